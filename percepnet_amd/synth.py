@@ -1,0 +1,66 @@
+"""Synthetic 48 kHz test/bench audio (SURVEY.md §8(d) "Synthetic inputs").
+
+The reference's two sample PCMs are absent (.MISSING_LARGE_BLOBS), so every parity and bench
+input is generated: stream ``s`` is a gated harmonic source with vibrato plus white noise;
+5 % of the streams are noise bursts with 1 s silences (exercises the ``silence`` branch,
+denoise.cpp:433,536) and 5 % are 200+300 Hz two-tone (pitch ambiguity for
+remove_doubling, pitch.cpp:424).  Values are int16 PCM, the CLI's format (main.cpp:30-34).
+"""
+import numpy as np
+
+FS = 48000
+FRAME = 480
+BASE_SEED = 20260925
+
+
+def stream_kind(s):
+    m = s % 20
+    if m == 7:
+        return "bursts"
+    if m == 13:
+        return "twotone"
+    return "voiced"
+
+
+def synth_stream(s, n_frames, base_seed=BASE_SEED):
+    """-> int16[n_frames*480] for stream index ``s``."""
+    rng = np.random.default_rng(base_seed + s)
+    n = n_frames * FRAME
+    t = np.arange(n) / FS
+    kind = stream_kind(s)
+    F = rng.uniform(80, 320)
+    a = rng.uniform(0.05, 0.5)
+    ns = rng.uniform(0.005, 0.1)
+    ph = rng.uniform(0, 1)
+    noise = rng.standard_normal(n)
+    if kind == "voiced":
+        f0 = F + 30.0 * np.sin(2 * np.pi * 0.7 * t)
+        phi = 2 * np.pi * np.cumsum(f0) / FS
+        v = ((t * 1.3 + ph) % 1.0 < 0.5).astype(np.float64)
+        x = np.zeros(n)
+        for k in range(1, 12):
+            x += (0.5 / k) * np.sin(k * phi)
+        x = a * v * x + ns * noise
+    elif kind == "bursts":
+        gate = (((t + ph) % 2.0) < 1.0).astype(np.float64)  # 1 s noise, 1 s digital silence
+        x = (a * 0.5) * gate * noise
+    else:
+        x = a * (0.5 * np.sin(2 * np.pi * 200 * t) + 0.5 * np.sin(2 * np.pi * 300 * t + ph)) + ns * noise
+    return np.clip(np.round(32768.0 * x), -32768, 32767).astype(np.int16)
+
+
+def synth_batch(n_streams, n_frames, first_stream=0, base_seed=BASE_SEED):
+    """-> int16[n_streams, n_frames*480]"""
+    return np.stack([synth_stream(first_stream + s, n_frames, base_seed) for s in range(n_streams)])
+
+
+def synth_batch_fast(n_streams, n_frames, seed=0):
+    """Cheap bench filler for very large batches: a small pool of distinct streams (all three
+    kinds) tiled to n_streams with per-stream sample rotation.  Parity never uses this."""
+    pool = synth_batch(min(n_streams, 64), n_frames, base_seed=BASE_SEED + 7919 * seed)
+    reps = (n_streams + pool.shape[0] - 1) // pool.shape[0]
+    out = np.tile(pool, (reps, 1))[:n_streams].copy()
+    for r in range(1, reps):
+        lo, hi = r * pool.shape[0], min((r + 1) * pool.shape[0], n_streams)
+        out[lo:hi] = np.roll(out[lo:hi], 37 * r, axis=1)
+    return out

@@ -1,0 +1,205 @@
+"""Weight ingestion for the PercepNet gain network, in the reference's ``nnet_data.h`` layout.
+
+The reference ships no pretrained model (README todo; ``src/nnet_data.cpp`` is absent), so the
+benchmark/parity weights are the ones BASELINE.md names: a ``torch.manual_seed(seed)``
+default-initialised network with the topology of ``rnn_train.py:105-121``, laid out exactly as
+``dump_percepnet.py`` lays it out in C:
+
+* Dense   ``input_weights[in*N + out]``            = ``weight.T``               (dump_percepnet.py:62)
+* Conv1d  ``input_weights[(k*Cin + c)*N + out]``   = ``weight.permute(2,1,0)``  (dump_percepnet.py:113)
+* GRU     ``input_weights[in*3N + gate*N + out]``, gates re-ordered torch (r,z,n) -> C (z,r,h)
+          (dump_percepnet.py:68-76); ``bias[6N] = cat(b_ih,b_hh).reshape(2,3,N)[:,[1,0,2]]`` (78-80)
+
+``printVector`` (dump_percepnet.py:32-49) prints each float32 through ``'{}'.format`` which
+yields the exact (double) decimal expansion of the float32, so the C compiler reads back the
+identical float32: the dump is value-preserving and no text round trip is needed here
+(checked against the reference's own dumper in tests/golden/make_golden.py).
+
+The binary container ("PNW1") is this repo's answer to the declared-but-never-defined
+``rnnoise_model_from_file`` (rnnoise.h:62): ten layer records in ``RNNModel`` order
+(nnet_data.h:6-26).
+"""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+# RNNModel order (nnet_data.h:6-26) with (kind, nb_inputs, nb_neurons, kernel_size, activation)
+ACT_LINEAR, ACT_SIGMOID, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+KIND_DENSE, KIND_CONV1D, KIND_GRU = 0, 1, 2
+LAYERS = [
+    ("fc", KIND_DENSE, 70, 128, 1, ACT_RELU),
+    ("conv1", KIND_CONV1D, 128, 512, 5, ACT_RELU),
+    ("conv2", KIND_CONV1D, 512, 512, 3, ACT_TANH),
+    ("gru1", KIND_GRU, 512, 512, 1, ACT_TANH),
+    ("gru2", KIND_GRU, 512, 512, 1, ACT_TANH),
+    ("gru3", KIND_GRU, 512, 512, 1, ACT_TANH),
+    ("gru_gb", KIND_GRU, 512, 512, 1, ACT_TANH),
+    ("gru_rb", KIND_GRU, 1024, 128, 1, ACT_TANH),
+    ("fc_gb", KIND_DENSE, 2560, 34, 1, ACT_SIGMOID),
+    ("fc_rb", KIND_DENSE, 128, 34, 1, ACT_SIGMOID),
+]
+MAGIC = b"PNW1"
+N_PARAMS = 7962564
+
+
+def _gru_kernel_to_c(kernel):
+    """torch [3N, in] (r,z,n) -> C [in, 3N] (z,r,h)."""
+    k_r, k_z, k_h = np.vsplit(kernel, 3)
+    return np.ascontiguousarray(np.hstack([k_z.T, k_r.T, k_h.T]))
+
+
+def _gru_bias_to_c(b_ih, b_hh):
+    b = np.concatenate([b_ih, b_hh]).reshape(2, 3, -1)
+    return np.ascontiguousarray(b[:, [1, 0, 2], :].reshape(-1))
+
+
+def build_torch_modules(seed=1234):
+    """Same construction order as rnn_train.PercepNet.__init__ so the RNG stream matches."""
+    import torch
+    from torch import nn
+
+    torch.manual_seed(seed)
+    mods = {}
+    mods["fc"] = nn.Linear(70, 128)
+    mods["conv1"] = nn.Conv1d(128, 512, 5, stride=1, padding=4)
+    mods["conv2"] = nn.Conv1d(512, 512, 3, stride=1, padding=2)
+    mods["gru1"] = nn.GRU(512, 512, 1, batch_first=True)
+    mods["gru2"] = nn.GRU(512, 512, 1, batch_first=True)
+    mods["gru3"] = nn.GRU(512, 512, 1, batch_first=True)
+    mods["gru_gb"] = nn.GRU(512, 512, 1, batch_first=True)
+    mods["gru_rb"] = nn.GRU(1024, 128, 1, batch_first=True)
+    mods["fc_gb"] = nn.Linear(512 * 5, 34)
+    mods["fc_rb"] = nn.Linear(128, 34)
+    return mods
+
+
+def modules_to_layers(mods, gain=1.0):
+    """-> dict name -> dict(bias, input_weights[, recurrent_weights]) as float32 C-layout arrays.
+
+    ``gain`` scales the *weights* (not biases) after layout; gain != 1 gives a "saturating"
+    weight set that drives the tanh/sigmoid table into its clamp (|x| > 8)."""
+    out = {}
+    for name, kind, nin, nn_, ks, act in LAYERS:
+        m = mods[name]
+        if kind == KIND_DENSE:
+            w = m.weight.detach().numpy().T
+            rec = None
+            b = m.bias.detach().numpy()
+        elif kind == KIND_CONV1D:
+            w = m.weight.detach().permute(2, 1, 0).numpy()
+            rec = None
+            b = m.bias.detach().numpy()
+        else:
+            w = _gru_kernel_to_c(m.weight_ih_l0.detach().numpy())
+            rec = _gru_kernel_to_c(m.weight_hh_l0.detach().numpy())
+            b = _gru_bias_to_c(m.bias_ih_l0.detach().numpy(), m.bias_hh_l0.detach().numpy())
+        d = {
+            "bias": np.ascontiguousarray(b, dtype=np.float32).reshape(-1),
+            "input_weights": (np.ascontiguousarray(w, dtype=np.float32).reshape(-1) * np.float32(gain)),
+        }
+        if rec is not None:
+            d["recurrent_weights"] = np.ascontiguousarray(rec, dtype=np.float32).reshape(-1) * np.float32(gain)
+        out[name] = d
+    return out
+
+
+def random_layers(seed, scale=None):
+    """Torch-free weights (numpy RNG), uniform(-1/sqrt(fan), 1/sqrt(fan)) like torch's default."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, kind, nin, nn_, ks, act in LAYERS:
+        if kind == KIND_GRU:
+            bound = 1.0 / np.sqrt(nn_)
+            d = {
+                "bias": rng.uniform(-bound, bound, 6 * nn_),
+                "input_weights": rng.uniform(-bound, bound, nin * 3 * nn_),
+                "recurrent_weights": rng.uniform(-bound, bound, nn_ * 3 * nn_),
+            }
+        else:
+            bound = 1.0 / np.sqrt(nin * ks)
+            d = {
+                "bias": rng.uniform(-bound, bound, nn_),
+                "input_weights": rng.uniform(-bound, bound, nin * ks * nn_),
+            }
+        if scale is not None:
+            for k in d:
+                if k != "bias":
+                    d[k] = d[k] * scale
+        out[name] = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in d.items()}
+    return out
+
+
+def pack_blob(layers):
+    """Serialise to the PNW1 container: magic, u32 n_layers, then per layer
+    ``u32 kind, nb_inputs, nb_neurons, kernel_size, activation, reset_after`` followed by the
+    float32 arrays bias, input_weights[, recurrent_weights]."""
+    parts = [MAGIC, struct.pack("<I", len(LAYERS))]
+    for name, kind, nin, nn_, ks, act in LAYERS:
+        d = layers[name]
+        parts.append(struct.pack("<6I", kind, nin, nn_, ks, act, 1 if kind == KIND_GRU else 0))
+        nb = 6 * nn_ if kind == KIND_GRU else nn_
+        assert d["bias"].size == nb, name
+        assert d["input_weights"].size == nin * ks * nn_ * (3 if kind == KIND_GRU else 1), name
+        parts.append(d["bias"].astype("<f4").tobytes())
+        parts.append(d["input_weights"].astype("<f4").tobytes())
+        if kind == KIND_GRU:
+            assert d["recurrent_weights"].size == nn_ * 3 * nn_, name
+            parts.append(d["recurrent_weights"].astype("<f4").tobytes())
+    return b"".join(parts)
+
+
+def unpack_blob(blob):
+    assert blob[:4] == MAGIC
+    (n,) = struct.unpack_from("<I", blob, 4)
+    off = 8
+    out = {}
+    for li in range(n):
+        kind, nin, nn_, ks, act, ra = struct.unpack_from("<6I", blob, off)
+        off += 24
+        name = LAYERS[li][0]
+        sizes = [("bias", 6 * nn_ if kind == KIND_GRU else nn_),
+                 ("input_weights", nin * ks * nn_ * (3 if kind == KIND_GRU else 1))]
+        if kind == KIND_GRU:
+            sizes.append(("recurrent_weights", nn_ * 3 * nn_))
+        d = {}
+        for key, sz in sizes:
+            d[key] = np.frombuffer(blob, dtype="<f4", count=sz, offset=off).copy()
+            off += 4 * sz
+        out[name] = d
+    assert off == len(blob)
+    return out
+
+
+def layer_digest(layers):
+    """sha256 per array, the unit compared with tests/golden/weights_seed1234.json."""
+    dg = {}
+    for name, *_ in LAYERS:
+        for k, v in layers[name].items():
+            dg[f"{name}.{k}"] = hashlib.sha256(v.astype("<f4").tobytes()).hexdigest()
+    return dg
+
+
+_CACHE = {}
+
+
+def default_blob(seed=1234, gain=1.0, cache_dir=None):
+    """The BASELINE.md weight set (seeded default-init PercepNet), cached on disk."""
+    key = (seed, gain)
+    if key in _CACHE:
+        return _CACHE[key]
+    cache_dir = cache_dir or os.environ.get("PERCEPNET_CACHE", "/tmp/percepnet_amd_cache")
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"pnw1_seed{seed}_gain{gain:g}.bin")
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            blob = f.read()
+    else:
+        blob = pack_blob(modules_to_layers(build_torch_modules(seed), gain))
+        tmp = path + f".{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)
+    _CACHE[key] = blob
+    return blob
