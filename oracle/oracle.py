@@ -1,0 +1,146 @@
+"""TEST INFRASTRUCTURE — ctypes loaders for the CPU oracle (oracle/liboracle.so, the C
+restatement) and for the compiled reference (oracle/_ref/libpercepnet_ref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product package (percepnet_amd/) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libpercepnet_ref.so")
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_s = ctypes.POINTER(ctypes.c_short)
+c_i = ctypes.POINTER(ctypes.c_int)
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_f)
+
+
+def build(force=False):
+    """Compile the C restatement, and the reference itself when /root/reference is present."""
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(HERE, "percepnet_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+class Oracle:
+    """The C restatement (percepnet_oracle.c)."""
+
+    def __init__(self, blob):
+        build()
+        self.lib = ctypes.CDLL(ORACLE_SO)
+        L = self.lib
+        L.pno_model_from_blob.restype = ctypes.c_void_p
+        L.pno_model_from_blob.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.pno_create.restype = ctypes.c_void_p
+        L.pno_create.argtypes = [ctypes.c_void_p]
+        L.pno_destroy.argtypes = [ctypes.c_void_p]
+        L.pno_process_frame.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
+        L.pno_run_pcm.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, c_s, c_f]
+        L.pno_run_float.argtypes = [ctypes.c_void_p, c_f, ctypes.c_int, c_f, c_f]
+        L.pno_frame_features.argtypes = [ctypes.c_void_p, c_f, c_f]
+        L.pno_frame_features.restype = ctypes.c_int
+        L.pno_compute_rnn.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
+        L.pno_remove_doubling.restype = ctypes.c_float
+        L.pno_remove_doubling.argtypes = [c_f, c_i, ctypes.c_int, ctypes.c_float]
+        L.pno_tansig.restype = ctypes.c_float
+        L.pno_tansig.argtypes = [ctypes.c_float]
+        L.pno_sigmoid.restype = ctypes.c_float
+        L.pno_sigmoid.argtypes = [ctypes.c_float]
+        L.pno_tansig_table.restype = c_f
+        self._blob = blob  # must outlive the model (borrowed pointers)
+        self.model = L.pno_model_from_blob(blob, len(blob)) if blob is not None else None
+        if blob is not None:
+            assert self.model, "bad PNW1 blob"
+
+    def run_pcm(self, pcm, want_gr=True):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        n = pcm.size // 480
+        out = np.zeros(max(n - 1, 0) * 480, np.int16)
+        gr = np.zeros((n, 68), np.float32)
+        self.lib.pno_run_pcm(self.model, pcm.ctypes.data_as(c_s), n, out.ctypes.data_as(c_s),
+                             _fp(gr) if want_gr else None)
+        return out, gr
+
+    def run_float(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // 480
+        out = np.zeros(n * 480, np.float32)
+        gr = np.zeros((n, 68), np.float32)
+        self.lib.pno_run_float(self.model, _fp(x), n, _fp(out), _fp(gr))
+        return out, gr
+
+    def features(self, x):
+        """Per-frame 70 features + silence flag, DSP only (no NN)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // 480
+        st = self.lib.pno_create(self.model)
+        feat = np.zeros((n, 70), np.float32)
+        sil = np.zeros(n, np.int32)
+        for t in range(n):
+            sil[t] = self.lib.pno_frame_features(st, _fp(x[t * 480:]), _fp(feat[t]))
+        self.lib.pno_destroy(st)
+        return feat, sil
+
+    def tables(self):
+        tw = c_f(); br = c_s(); hw = c_f(); ch = c_f(); bd = c_i()
+        self.lib.pno_tables(ctypes.byref(tw), ctypes.byref(br), ctypes.byref(hw), ctypes.byref(ch),
+                            ctypes.byref(bd))
+        return (np.ctypeslib.as_array(tw, (960, 2)).copy(), np.ctypeslib.as_array(br, (960,)).copy(),
+                np.ctypeslib.as_array(hw, (480,)).copy(), np.ctypeslib.as_array(ch, (7,)).copy(),
+                np.ctypeslib.as_array(bd, (34,)).copy())
+
+    def tansig_table(self):
+        return np.ctypeslib.as_array(self.lib.pno_tansig_table(), (201,)).copy()
+
+
+def ref_available():
+    if not os.path.exists(REF_SO) and os.path.isdir("/root/reference/src"):
+        build()
+    return os.path.exists(REF_SO)
+
+
+class Reference:
+    """The reference itself (untouched sources compiled by oracle/Makefile `ref`)."""
+
+    def __init__(self, blob):
+        assert ref_available(), "oracle/_ref/libpercepnet_ref.so not built"
+        self.lib = ctypes.CDLL(REF_SO)
+        L = self.lib
+        L.ref_load_weights.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.ref_create.restype = ctypes.c_void_p
+        L.ref_destroy.argtypes = [ctypes.c_void_p]
+        L.ref_process_frame.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
+        L.ref_run_pcm.argtypes = [c_s, ctypes.c_int, c_s, c_f]
+        L.ref_run_float.argtypes = [c_f, ctypes.c_int, c_f, c_f]
+        L.ref_compute_rnn.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
+        L.ref_remove_doubling.restype = ctypes.c_float
+        L.ref_remove_doubling.argtypes = [c_f, c_i, ctypes.c_int, ctypes.c_float]
+        if blob is not None:
+            rc = L.ref_load_weights(blob, len(blob))
+            assert rc == 0, rc
+
+    def run_pcm(self, pcm, want_gr=True):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        n = pcm.size // 480
+        out = np.zeros(max(n - 1, 0) * 480, np.int16)
+        gr = np.zeros((n, 68), np.float32)
+        self.lib.ref_run_pcm(pcm.ctypes.data_as(c_s), n, out.ctypes.data_as(c_s), _fp(gr) if want_gr else None)
+        return out, gr
+
+    def run_float(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // 480
+        out = np.zeros(n * 480, np.float32)
+        gr = np.zeros((n, 68), np.float32)
+        self.lib.ref_run_float(_fp(x), n, _fp(out), _fp(gr))
+        return out, gr

@@ -1,0 +1,107 @@
+"""Regenerate tests/golden/* from the reference itself.  Runs ONLY in the build container
+(needs /root/reference); the outputs are committed so the GPU box never needs the reference.
+
+    python tests/golden/make_golden.py
+
+Produces
+  weights_seed1234.json   sha256 per weight array of the seeded default-init PercepNet, obtained
+                          by importing the reference's own rnn_train.PercepNet + dump_percepnet
+                          (with sys.modules stubs for the absent h5py/tensorboardX/torchvision),
+                          writing the C text with its dumper and parsing that text back.
+  nnet_kat.json           the known-answer vectors of tests/nnet_data_test.h (the only golden
+                          vectors the reference's own tests hold, tests/testnnet.cpp:19-66).
+  tables.npz              tansig_table.h values, FFT twiddles/bitrev/factors from the compiled
+                          reference (oracle/_ref).
+  pcm_golden.npz          int16 PCM in / PCM out / g,r tap of the compiled reference
+                          (percepNet_run semantics) for streams 0 (voiced), 7 (bursts+silence),
+                          13 (two-tone), 48 frames each, plus float-in/float-out of stream 0.
+"""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def parse_c_arrays(text):
+    out = {}
+    for m in re.finditer(r"static const float (\w+)\[(\d+)\] = \{(.*?)\};", text, re.S):
+        vals = np.array([float(v) for v in m.group(3).replace("\n", " ").split(",")], dtype=np.float64)
+        assert vals.size == int(m.group(2))
+        out[m.group(1)] = vals.astype(np.float32)
+    return out
+
+
+def golden_weights(seed=1234):
+    for mod in ["h5py", "tensorboardX", "torchvision", "torchvision.transforms"]:
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["torchvision.transforms"].ToTensor = object
+    sys.path.insert(0, REF)
+    import torch
+    import dump_percepnet  # noqa: F401  (patches .dump_data onto torch modules)
+    import rnn_train
+
+    torch.manual_seed(seed)
+    model = rnn_train.PercepNet()
+    digests = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, module in model.named_children():
+            path = os.path.join(td, name + ".c")
+            with open(path, "w") as f:
+                module.dump_data(f, name)
+            arrs = parse_c_arrays(open(path).read())
+            for k, v in arrs.items():
+                # dumper names: <layer>_weights / _recurrent_weights / _bias
+                key = k.replace(name + "_", name + ".", 1)
+                key = key.replace(".weights", ".input_weights")
+                digests[key] = hashlib.sha256(v.astype("<f4").tobytes()).hexdigest()
+    return digests
+
+
+def main():
+    from percepnet_amd import weights, synth
+    from oracle.oracle import Reference, _fp, c_s
+
+    dg = golden_weights(1234)
+    mine = weights.layer_digest(weights.modules_to_layers(weights.build_torch_modules(1234)))
+    assert dg == mine, "percepnet_amd.weights does not reproduce the reference dumper"
+    json.dump({"seed": 1234, "sha256": dg}, open(os.path.join(HERE, "weights_seed1234.json"), "w"), indent=1)
+
+    kat_txt = open(os.path.join(REF, "tests", "nnet_data_test.h")).read()
+    kat = {k: [float(x) for x in v.astype(np.float64)] for k, v in parse_c_arrays(kat_txt).items()}
+    json.dump(kat, open(os.path.join(HERE, "nnet_kat.json"), "w"), indent=1)
+
+    blob = weights.default_blob(1234)
+    ref = Reference(blob)
+    tw = np.zeros((960, 2), np.float32); br = np.zeros(960, np.int16); fac = np.zeros(16, np.int16)
+    ref.lib.ref_fft_tables(_fp(tw), br.ctypes.data_as(c_s), fac.ctypes.data_as(c_s))
+    tansig = np.array([np.float32(float(v[:-1])) for v in
+                       re.findall(r"[0-9.]+f", open(os.path.join(REF, "src", "tansig_table.h")).read())], np.float32)
+    assert tansig.size == 201
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), twiddles=tw, bitrev=br, factors=fac[:10], tansig=tansig)
+
+    g = {}
+    for s in (0, 7, 13):
+        pcm = synth.synth_stream(s, 48)
+        out, gr = ref.run_pcm(pcm)
+        g[f"in_{s}"] = pcm; g[f"out_{s}"] = out; g[f"gr_{s}"] = gr
+    x = synth.synth_stream(0, 48).astype(np.float32) / np.float32(32768)
+    fo, fgr = ref.run_float(x)
+    g["fin_0"] = x; g["fout_0"] = fo
+    np.savez_compressed(os.path.join(HERE, "pcm_golden.npz"), **g)
+    print("golden written")
+
+
+if __name__ == "__main__":
+    main()

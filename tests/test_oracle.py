@@ -1,0 +1,120 @@
+"""CPU tests of the oracle (oracle/percepnet_oracle.c): against the committed golden vectors that
+the compiled reference produced (tests/golden/make_golden.py), against the reference's own
+known-answer fixture (tests/nnet_data_test.h -> nnet_kat.json), and — when oracle/_ref is present
+— bit-for-bit against the compiled reference on fresh inputs."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, Reference, _fp, c_f, ref_available
+from percepnet_amd import synth, weights
+
+
+def test_weights_match_reference_dumper(golden_dir):
+    dg = json.load(open(os.path.join(golden_dir, "weights_seed1234.json")))["sha256"]
+    mine = weights.layer_digest(weights.modules_to_layers(weights.build_torch_modules(1234)))
+    assert mine == dg
+    blob = weights.default_blob(1234)
+    assert weights.layer_digest(weights.unpack_blob(blob)) == dg
+    assert sum(v.size for d in weights.unpack_blob(blob).values() for v in d.values()) == weights.N_PARAMS
+
+
+def test_tables_match_reference(oracle, golden_dir):
+    t = np.load(os.path.join(golden_dir, "tables.npz"))
+    tw, br, hw, ch, bd = oracle.tables()
+    assert np.array_equal(tw.view(np.uint32), t["twiddles"].view(np.uint32))
+    assert np.array_equal(br, t["bitrev"])
+    assert list(t["factors"]) == [5, 192, 3, 64, 4, 16, 4, 4, 4, 1]
+    assert np.array_equal(oracle.tansig_table(), t["tansig"])
+    # SURVEY §8 a3 [probe]
+    assert list(bd) == [0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 31, 36, 41, 48, 56, 65, 75,
+                        86, 99, 115, 132, 152, 175, 201, 230, 265, 304, 349, 400]
+    assert abs(float(ch.sum()) - 1) < 1e-6 and hw[0] > 0 and abs(hw[-1] - 1) < 1e-5
+
+
+def test_nnet_known_answers(oracle, golden_dir):
+    """The reference's own gtest cases (tests/testnnet.cpp:19-66), eps 1e-5."""
+    k = {n: np.array(v, np.float32) for n, v in json.load(open(os.path.join(golden_dir, "nnet_kat.json"))).items()}
+    L = oracle.lib
+    half2 = np.full(2, .5, np.float32)
+    out = np.zeros(3, np.float32)
+    L.pno_dense(_fp(k["fc_bias"]), _fp(k["fc_weights"]), 2, 3, 1, _fp(out), _fp(half2))
+    assert np.abs(out - k["fc_output"]).max() < 1e-5
+    mem = np.zeros(6, np.float32)
+    for push, row in ((1, None), (2, 0), (3, 1)):
+        L.pno_conv1d(_fp(k["conv1_bias"]), _fp(k["conv1_weights"]), 2, 3, 3, 1, _fp(out), _fp(mem), _fp(half2))
+        if row is not None:
+            assert np.abs(out - k["conv1_output"][3 * row:3 * row + 3]).max() < 1e-5
+    st = np.zeros(3, np.float32)
+    for step in range(3):  # the reference asserts steps 0,1 one-sidedly; all three hold two-sided
+        L.pno_gru(_fp(k["gru1_bias"]), _fp(k["gru1_weights"]), _fp(k["gru1_recurrent_weights"]), 2, 3, 2,
+                  _fp(st), _fp(half2))
+        assert np.abs(st - k["gru1_output"][3 * step:3 * step + 3]).max() < 1e-5
+
+
+def test_oracle_matches_golden_pcm(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
+    for s in (0, 7, 13):
+        assert np.array_equal(synth.synth_stream(s, 48), g[f"in_{s}"]), "synthetic generator drifted"
+        out, gr = oracle.run_pcm(g[f"in_{s}"])
+        assert np.array_equal(out, g[f"out_{s}"])
+        assert np.array_equal(gr.view(np.uint32), g[f"gr_{s}"].view(np.uint32))
+    fo, _ = oracle.run_float(g["fin_0"])
+    assert np.array_equal(fo.view(np.uint32), g["fout_0"].view(np.uint32))
+
+
+def test_activation_table_edges(oracle):
+    L = oracle.lib
+    assert L.pno_tansig(0.0) == 0.0
+    assert abs(L.pno_tansig(100.0) - 1.0) < 1e-5 and abs(L.pno_tansig(-100.0) + 1.0) < 1e-5
+    xs = np.linspace(-9, 9, 2001)
+    ys = np.array([L.pno_tansig(float(x)) for x in xs])
+    assert np.abs(ys - np.tanh(xs)).max() < 2e-4  # table + 2nd-order correction (vec.h:53-70)
+    assert abs(L.pno_sigmoid(0.0) - .5) < 1e-7
+
+
+@pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_bit_exact_vs_compiled_reference(blob, oracle):
+    ref = Reference(blob)
+    for s in (1, 27, 33, 47):  # voiced, bursts, two-tone, voiced — not the golden streams
+        pcm = synth.synth_stream(s, 120)
+        a, ga = oracle.run_pcm(pcm)
+        b, gb = ref.run_pcm(pcm)
+        assert np.array_equal(a, b), s
+        assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), s
+
+
+@pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no /root/reference)")
+def test_oracle_stages_vs_compiled_reference(blob, oracle):
+    ref = Reference(blob)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((960, 2)).astype(np.float32)
+    a = np.zeros_like(x); b = np.zeros_like(x)
+    oracle.lib.pno_fft960(_fp(x), _fp(a)); ref.lib.ref_fft960(_fp(x), _fp(b))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    sig = synth.synth_stream(2, 30).astype(np.float32) / 32768
+    prev_p, prev_g = 300, np.float32(0.4)
+    for off in range(0, 10000, 997):
+        buf = sig[off:off + 1728].copy()
+        la = np.zeros(864, np.float32); lb = np.zeros(864, np.float32)
+        oracle.lib.pno_pitch_downsample(_fp(buf), _fp(la)); ref.lib.ref_pitch_downsample(_fp(buf), _fp(lb))
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+        pa = ctypes.c_int(); pb = ctypes.c_int(); ca = ctypes.c_float(); cb = ctypes.c_float()
+        oracle.lib.pno_pitch_search(_fp(la), ctypes.byref(pa), ctypes.byref(ca))
+        ref.lib.ref_pitch_search(_fp(lb), ctypes.byref(pb), ctypes.byref(cb))
+        assert pa.value == pb.value and ca.value == cb.value
+        ta = ctypes.c_int(768 - pa.value); tb = ctypes.c_int(768 - pb.value)
+        ga = oracle.lib.pno_remove_doubling(_fp(la), ctypes.byref(ta), prev_p, prev_g)
+        gb = ref.lib.ref_remove_doubling(_fp(lb), ctypes.byref(tb), prev_p, prev_g)
+        assert ta.value == tb.value and ga == gb
+        prev_p, prev_g = ta.value, np.float32(ga)
+    # saturating weights drive the tanh table into its clamp
+    sat = weights.pack_blob(weights.random_layers(3, scale=6.0))
+    o2 = Oracle(sat); r2 = Reference(sat)
+    pcm = synth.synth_stream(4, 40)
+    a, ga = o2.run_pcm(pcm); b, gb = r2.run_pcm(pcm)
+    assert np.array_equal(a, b) and np.array_equal(ga.view(np.uint32), gb.view(np.uint32))
+    assert ga.min() < 0.02 and ga.max() > 0.98
