@@ -1,0 +1,118 @@
+/* libpercepnet_hip.so — C-ABI of the MI355X-native batched PercepNet inference path.
+ *
+ * Two layers of entry points:
+ *
+ *  (1) The reference's own frame-engine interface (reference src/rnnoise.h:49-68), same names,
+ *      argument meaning and return values, so existing callers (reference src/main.cpp:30-39)
+ *      re-link unchanged.  The reference compiles its "C" API as C++ (no extern "C" in
+ *      rnnoise.h), so its exported symbols are Itanium-mangled; this library exports BOTH the
+ *      mangled names (csrc/rnnoise_compat.cpp) and the extern "C" ones declared below with a
+ *      pn_ prefix-free alias set (`rnnoise_*_c`).
+ *
+ *  (2) The batched interface the GPU needs: one context = B independent 48 kHz streams advanced
+ *      in lock-step, one 10 ms frame (480 samples) per stream per call.  Plain pointers and
+ *      sizes only; device pointers are raw HIP device addresses (e.g. torch's data_ptr()).
+ *
+ * All functions are thread-compatible per context; one context belongs to one HIP device.
+ * Errors: functions returning int give 0 on success, <0 on failure; pn_last_error() returns a
+ * thread-local description.  The library never falls back to a CPU path: if no HIP device is
+ * usable, context creation fails.
+ */
+#ifndef PERCEPNET_HIP_H
+#define PERCEPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "percepnet_nnet_data.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_FRAME_SIZE 480      /* reference denoise.cpp:19 */
+#define PN_NB_BANDS 34         /* reference denoise.cpp:35 */
+#define PN_NB_FEATURES 70      /* reference denoise.cpp:40 */
+
+typedef struct pn_ctx pn_ctx;
+typedef struct pn_model pn_model;
+
+/* Network evaluation mode. */
+enum {
+  PN_NN_MFMA = 0,    /* fp32 MFMA GEMM over the stream batch (v_mfma_f32_32x32x2_f32): each output
+                        is a k-ascending fmaf chain from the bias — the reference's summation
+                        order (nnet.cpp:59-72) with fused instead of separate rounding */
+  PN_NN_STRICT = 1   /* one lane per (stream, neuron), separate mul and add in the reference's
+                        order: bit-identical to the CPU reference; slow, for parity tests */
+};
+
+/* ---- models ------------------------------------------------------------------------------ */
+/* Borrow an in-memory RNNModel laid out as nnet_data.h lays it out (replaces the reference's
+   link-time `percepnet_model_orig`, denoise.cpp:49-51,267).  The arrays are copied. */
+pn_model *pn_model_from_rnnmodel(const RNNModel *m);
+/* Load the PNW1 container (percepnet_amd/weights.py) — this library's implementation of the
+   declared-but-undefined rnnoise_model_from_file (rnnoise.h:62). */
+pn_model *pn_model_from_blob(const void *blob, size_t nbytes);
+pn_model *pn_model_from_file(FILE *f);
+void pn_model_free(pn_model *m);
+
+/* ---- batched contexts ---------------------------------------------------------------------- */
+/* device: HIP device ordinal; n_streams >= 1; stream: a hipStream_t to launch on (NULL = the
+   context creates its own non-blocking stream).  State starts all-zero (rnnoise_init,
+   denoise.cpp:259-280). */
+pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream);
+void pn_ctx_destroy(pn_ctx *ctx);
+int pn_ctx_reset(pn_ctx *ctx);                       /* zero all stream state, frame counter = 0 */
+int pn_ctx_n_streams(const pn_ctx *ctx);
+int64_t pn_ctx_frames_done(const pn_ctx *ctx);
+size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state + weights */
+
+/* Advance every stream by one frame.  Device-resident buffers, asynchronous on the context's
+   stream.  in: [n_streams][480]; out: [n_streams][480]; gr (optional, may be NULL):
+   [n_streams][68] = g[34] | r[34], the reference's feature_test.raw tap (denoise.cpp:533-534).
+   f32 = the rnnoise_process_frame sample convention (nominal [-1,1));
+   i16 = the CLI convention (main.cpp:34,36): in/32768.f, out = trunc(x*32768) wrapped to 16 bit.
+   in and out may alias. */
+int pn_process_f32(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr);
+int pn_process_i16(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr);
+/* n_frames consecutive frames per call: in/out are [n_frames][n_streams][480] (frame-major). */
+int pn_process_i16_multi(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr, int n_frames);
+/* Host-buffer convenience wrappers (H2D, process, D2H, synchronise). */
+int pn_process_host_f32(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr);
+int pn_process_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr);
+int pn_ctx_synchronize(pn_ctx *ctx);
+
+/* Mid-pipeline taps for per-stage parity tests (device -> host copies, synchronising).
+   features: [n_streams][70] of the last frame; silence: [n_streams] int32. */
+int pn_ctx_read_features(pn_ctx *ctx, float *h_feat, int32_t *h_silence);
+/* Run only the network on host-supplied features [n_streams][70] -> g,r [n_streams][68]. */
+int pn_ctx_compute_rnn_host(pn_ctx *ctx, const float *h_feat, float *h_gr);
+
+/* ---- per-kernel timing (HIP events on the context's stream) ------------------------------- */
+/* When enabled, every launch of the named kernel families is bracketed by events. */
+int pn_ctx_set_profiling(pn_ctx *ctx, int enable);
+/* name: one of pn_kernel_name(i), i in [0, pn_kernel_count()).  Returns total milliseconds and
+   launch count since the last pn_ctx_reset_profile (synchronises the stream). */
+int pn_kernel_count(void);
+const char *pn_kernel_name(int i);
+int pn_ctx_kernel_time(pn_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+int pn_ctx_reset_profile(pn_ctx *ctx);
+
+const char *pn_last_error(void);
+const char *pn_version(void);
+
+/* ---- reference frame-engine interface, extern "C" spelling -------------------------------- */
+/* (the C++-mangled rnnoise_* symbols with the reference's exact prototypes are exported too) */
+typedef struct DenoiseState DenoiseState;
+int rnnoise_get_size_c(void);
+int rnnoise_init_c(DenoiseState *st, RNNModel *model);
+DenoiseState *rnnoise_create_c(RNNModel *model);
+void rnnoise_destroy_c(DenoiseState *st);
+float rnnoise_process_frame_c(DenoiseState *st, float *out, const float *in, FILE *f_feature);
+RNNModel *rnnoise_model_from_file_c(FILE *f);
+void rnnoise_model_free_c(RNNModel *model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,187 @@
+"""ctypes binding of libpercepnet_hip.so (include/percepnet_hip.h) — the host-side mirror of the
+reference's frame-engine interface for Python callers (tests, bench).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is usable, loading /
+context creation raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpercepnet_hip.so")
+
+NN_MFMA, NN_STRICT = 0, 1
+FRAME = 480
+
+_vp = ctypes.c_void_p
+_lib = None
+
+
+class PercepNetError(RuntimeError):
+    pass
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PercepNetError(
+            f"{LIB_PATH} is missing: build it with `python -m percepnet_amd.build` (no CPU fallback exists)")
+    L = ctypes.CDLL(LIB_PATH)
+    L.pn_last_error.restype = ctypes.c_char_p
+    L.pn_version.restype = ctypes.c_char_p
+    L.pn_model_from_blob.restype = _vp
+    L.pn_model_from_blob.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.pn_model_free.argtypes = [_vp]
+    L.pn_ctx_create.restype = _vp
+    L.pn_ctx_create.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
+    L.pn_ctx_destroy.argtypes = [_vp]
+    L.pn_ctx_reset.argtypes = [_vp]
+    L.pn_ctx_n_streams.argtypes = [_vp]
+    L.pn_ctx_frames_done.restype = ctypes.c_int64
+    L.pn_ctx_frames_done.argtypes = [_vp]
+    L.pn_ctx_device_bytes.restype = ctypes.c_size_t
+    L.pn_ctx_device_bytes.argtypes = [_vp]
+    for name in ("pn_process_f32", "pn_process_i16", "pn_process_host_f32", "pn_process_host_i16"):
+        getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
+    L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
+    L.pn_ctx_synchronize.argtypes = [_vp]
+    L.pn_ctx_read_features.argtypes = [_vp, _vp, _vp]
+    L.pn_ctx_compute_rnn_host.argtypes = [_vp, _vp, _vp]
+    L.pn_ctx_set_profiling.argtypes = [_vp, ctypes.c_int]
+    L.pn_kernel_name.restype = ctypes.c_char_p
+    L.pn_kernel_name.argtypes = [ctypes.c_int]
+    L.pn_ctx_kernel_time.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_int64)]
+    L.pn_ctx_reset_profile.argtypes = [_vp]
+    _lib = L
+    return L
+
+
+def _err(L):
+    return L.pn_last_error().decode(errors="replace")
+
+
+class Model:
+    def __init__(self, blob):
+        self.L = load_library()
+        self.h = self.L.pn_model_from_blob(blob, len(blob))
+        if not self.h:
+            raise PercepNetError(_err(self.L))
+
+    def close(self):
+        if self.h:
+            self.L.pn_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """B independent streams advanced one 10 ms frame per call (pn_ctx)."""
+
+    def __init__(self, model, n_streams, device=0, nn_mode=NN_MFMA, stream=None):
+        self.L = model.L
+        self.model = model
+        self.n_streams = int(n_streams)
+        self.h = self.L.pn_ctx_create(model.h, device, self.n_streams, nn_mode, stream)
+        if not self.h:
+            raise PercepNetError(_err(self.L))
+
+    def close(self):
+        if self.h:
+            self.L.pn_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PercepNetError(_err(self.L))
+
+    def reset(self):
+        self._chk(self.L.pn_ctx_reset(self.h))
+
+    def synchronize(self):
+        self._chk(self.L.pn_ctx_synchronize(self.h))
+
+    def device_bytes(self):
+        return self.L.pn_ctx_device_bytes(self.h)
+
+    # device-pointer entry points (ints, e.g. torch.Tensor.data_ptr())
+    def process_i16_dev(self, d_in, d_out, d_gr=None):
+        self._chk(self.L.pn_process_i16(self.h, d_in, d_out, d_gr))
+
+    def process_f32_dev(self, d_in, d_out, d_gr=None):
+        self._chk(self.L.pn_process_f32(self.h, d_in, d_out, d_gr))
+
+    # host numpy entry points
+    def process_i16(self, frame, want_gr=True):
+        frame = np.ascontiguousarray(frame, dtype=np.int16).reshape(self.n_streams, FRAME)
+        out = np.empty_like(frame)
+        gr = np.empty((self.n_streams, 68), np.float32) if want_gr else None
+        self._chk(self.L.pn_process_host_i16(self.h, frame.ctypes.data, out.ctypes.data,
+                                             gr.ctypes.data if want_gr else None))
+        return out, gr
+
+    def process_f32(self, frame, want_gr=True):
+        frame = np.ascontiguousarray(frame, dtype=np.float32).reshape(self.n_streams, FRAME)
+        out = np.empty_like(frame)
+        gr = np.empty((self.n_streams, 68), np.float32) if want_gr else None
+        self._chk(self.L.pn_process_host_f32(self.h, frame.ctypes.data, out.ctypes.data,
+                                             gr.ctypes.data if want_gr else None))
+        return out, gr
+
+    def run_pcm(self, pcm):
+        """percepNet_run semantics (main.cpp:30-39) for a batch: pcm int16 [B, n_frames*480] ->
+        (out int16 [B, (n_frames-1)*480] with the first output frame dropped, gr [B, n_frames, 68])."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.n_streams, -1)
+        n = pcm.shape[1] // FRAME
+        out = np.zeros((self.n_streams, max(n - 1, 0) * FRAME), np.int16)
+        gr = np.zeros((self.n_streams, n, 68), np.float32)
+        for t in range(n):
+            o, g = self.process_i16(pcm[:, t * FRAME:(t + 1) * FRAME])
+            gr[:, t] = g
+            if t > 0:
+                out[:, (t - 1) * FRAME:t * FRAME] = o
+        return out, gr
+
+    def read_features(self):
+        feat = np.empty((self.n_streams, 70), np.float32)
+        sil = np.empty(self.n_streams, np.int32)
+        self._chk(self.L.pn_ctx_read_features(self.h, feat.ctypes.data, sil.ctypes.data))
+        return feat, sil
+
+    def compute_rnn(self, feat):
+        feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(self.n_streams, 70)
+        gr = np.empty((self.n_streams, 68), np.float32)
+        self._chk(self.L.pn_ctx_compute_rnn_host(self.h, feat.ctypes.data, gr.ctypes.data))
+        return gr
+
+    def set_profiling(self, on):
+        self._chk(self.L.pn_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def reset_profile(self):
+        self._chk(self.L.pn_ctx_reset_profile(self.h))
+
+    def kernel_times(self):
+        """-> {family: (total_ms, launches)} from HIP events on the context's stream."""
+        out = {}
+        for i in range(self.L.pn_kernel_count()):
+            name = self.L.pn_kernel_name(i)
+            ms = ctypes.c_double()
+            n = ctypes.c_int64()
+            self._chk(self.L.pn_ctx_kernel_time(self.h, name, ctypes.byref(ms), ctypes.byref(n)))
+            out[name.decode()] = (ms.value, n.value)
+        return out

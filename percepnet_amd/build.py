@@ -1,0 +1,73 @@
+"""Build libpercepnet_hip.so for gfx950 with hipcc (in-tree, so the .so travels to the GPU box).
+
+    python -m percepnet_amd.build [--force]
+
+Flags that matter for parity (DESIGN.md "Numerics"):
+  -ffp-contract=off   the DSP and STRICT kernels must round every multiply and add separately,
+                      like the reference's x86-64 SSE2 build; MFMA is an explicit builtin and is
+                      unaffected
+  (defaults kept)     correctly rounded fp32 divide/sqrt, fp32 denormals preserved
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libpercepnet_hip.so")
+RUN = os.path.join(LIBDIR, "percepnet_run")
+SOURCES = ["pn_tables.cpp", "pn_dsp.hip", "pn_nn.hip", "pn_context.cpp", "rnnoise_compat.cpp"]
+# percepnet_run.cpp (the CLI) is linked separately against the library
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(HERE, "..", "include", "percepnet_hip.h"),
+        os.path.join(HERE, "..", "include", "percepnet_nnet_data.h")]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        if force or _stale(o, deps):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    cli = os.path.join(CSRC, "percepnet_run.cpp")
+    if os.path.exists(cli) and (force or _stale(RUN, [cli, LIB])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", cli, "-o", RUN, "-L" + LIBDIR,
+               "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,58 @@
+// Internal shared definitions for libpercepnet_hip (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define PN_FRAME 480
+#define PN_WINDOW 960
+#define PN_FREQ 481
+#define PN_NB 34
+#define PN_NFEAT 70
+#define PN_FEAT_STRIDE 96       // features padded with zeros to a multiple of the GEMM K-tile (32)
+#define PN_NFFT 960
+#define PN_HIST_FRAMES 12       // comb_buf = 5760 samples = 12 frames (denoise.cpp:32), kept as a ring
+#define PN_HIST (PN_HIST_FRAMES * PN_FRAME)
+#define PN_SPEC_BINS 400        // bins >= 400 never contribute (denoise.cpp:89-182)
+#define PN_PITCH_MAX 768
+#define PN_PITCH_MIN 60
+#define PN_COMB_M 3
+
+// Read-only tables shared by all streams (CommonState + erb_band, denoise.cpp:61-69,87,186-214).
+// Computed on the host in double exactly as the reference computes them, uploaded once.
+struct PnTables {
+  float tw[PN_NFFT * 2];          // twiddles (r,i) kiss_fft.cpp:406-421
+  float half_window[PN_FRAME];    // denoise.cpp:191-192
+  float comb_hann[8];             // 7 used, denoise.cpp:200-206
+  float tansig[208];              // 201 used, tansig_table.h
+  float bin_frac[PN_SPEC_BINS];   // (float)j / band_size for bin = border[i] + j
+  int16_t bitrev[PN_NFFT];        // digit-reversal scatter index kiss_fft.cpp:315-345
+  int16_t border[PN_NB + 2];      // ERBBand::nfftborder erbband.h:63-75
+  uint8_t bin_band[PN_SPEC_BINS]; // band i with border[i] <= bin < border[i+1]
+};
+
+void pn_build_tables(PnTables *t);
+
+// Network geometry (rnn_train.py:105-121 / rnn.cpp:42-81)
+enum { PN_L_FC, PN_L_CONV1, PN_L_CONV2, PN_L_GRU1, PN_L_GRU2, PN_L_GRU3, PN_L_GRU_GB, PN_L_GRU_RB,
+       PN_L_FC_GB, PN_L_FC_RB, PN_NLAYERS };
+enum { PN_KIND_DENSE = 0, PN_KIND_CONV1D = 1, PN_KIND_GRU = 2 };
+
+struct PnLayerHost {
+  int kind, nin, nn, ks, act, reset_after;
+  const float *bias, *w, *rw;   // host pointers into the model's own copy (nnet_data.h layouts)
+};
+
+struct pn_model {
+  PnLayerHost L[PN_NLAYERS];
+  float *storage;               // one malloc holding every array
+  size_t n_floats;
+};
+
+#define PN_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) { pn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return -1; } \
+  } while (0)
+
+void pn_set_error(const char *fmt, ...);

@@ -1,0 +1,432 @@
+// Host side of libpercepnet_hip: models, batched contexts, the per-frame launch sequence and the
+// C-ABI declared in include/percepnet_hip.h.  Mirrors the reference's frame engine
+// (rnnoise_create/init/process_frame, denoise.cpp:252-280,508-547) for B streams in lock-step.
+#include "pn_common.h"
+#include "../../include/percepnet_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+// ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
+struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
+void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int frame_t, const void *in, int in_is_i16,
+                        float *hist, float2 *Xs, float2 *Ps, float *feat, int *silence, int *last_period,
+                        float *last_gain);
+void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
+                       const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
+size_t pn_packed_floats(int K, int ncols, int ct_round);
+void pn_pack_weights(const float *W, int K, int ncols, int ct_round, float *Wp);
+int pn_dense_nt(int N);
+void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows);
+void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
+                   const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
+                   float *h_new, int n_rows);
+
+// ---- errors -----------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void pn_set_error(const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char *pn_last_error(void) { return g_err; }
+extern "C" const char *pn_version(void) { return "percepnet_hip 0.1 (gfx950)"; }
+
+// ---- models -------------------------------------------------------------------------------------------
+static const struct { int kind, nin, nn, ks; } kGeom[PN_NLAYERS] = {
+  {PN_KIND_DENSE, 70, 128, 1}, {PN_KIND_CONV1D, 128, 512, 5}, {PN_KIND_CONV1D, 512, 512, 3},
+  {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1},
+  {PN_KIND_GRU, 1024, 128, 1}, {PN_KIND_DENSE, 2560, 34, 1}, {PN_KIND_DENSE, 128, 34, 1}};
+
+static size_t layer_floats(int kind, int nin, int nn, int ks, size_t *nb, size_t *nw, size_t *nr) {
+  *nb = kind == PN_KIND_GRU ? 6 * (size_t)nn : (size_t)nn;
+  *nw = (size_t)nin * ks * nn * (kind == PN_KIND_GRU ? 3 : 1);
+  *nr = kind == PN_KIND_GRU ? (size_t)nn * 3 * nn : 0;
+  return *nb + *nw + *nr;
+}
+
+static int check_geometry(int li, int kind, int nin, int nn, int ks) {
+  if (kind != kGeom[li].kind || nin != kGeom[li].nin || nn != kGeom[li].nn || ks != kGeom[li].ks) {
+    pn_set_error("layer %d: geometry %d/%d/%d/%d differs from the PercepNet topology (rnn.cpp:42-81 hard-codes it)",
+                 li, kind, nin, nn, ks);
+    return -1;
+  }
+  return 0;
+}
+
+struct LayerSrc { int kind, nin, nn, ks, act, reset_after; const float *bias, *w, *rw; };
+
+static pn_model *model_from_sources(const LayerSrc *src) {
+  size_t total = 0;
+  for (int li = 0; li < PN_NLAYERS; li++) {
+    size_t nb, nw, nr;
+    if (check_geometry(li, src[li].kind, src[li].nin, src[li].nn, src[li].ks)) return NULL;
+    if (src[li].kind == PN_KIND_GRU && !src[li].reset_after) { pn_set_error("only reset_after GRUs are supported (dump_percepnet.py:94-98)"); return NULL; }
+    total += layer_floats(src[li].kind, src[li].nin, src[li].nn, src[li].ks, &nb, &nw, &nr);
+  }
+  pn_model *m = (pn_model *)calloc(1, sizeof(pn_model));
+  m->storage = (float *)malloc(total * sizeof(float));
+  m->n_floats = total;
+  float *p = m->storage;
+  for (int li = 0; li < PN_NLAYERS; li++) {
+    size_t nb, nw, nr;
+    layer_floats(src[li].kind, src[li].nin, src[li].nn, src[li].ks, &nb, &nw, &nr);
+    PnLayerHost &L = m->L[li];
+    L.kind = src[li].kind; L.nin = src[li].nin; L.nn = src[li].nn; L.ks = src[li].ks; L.act = src[li].act;
+    L.reset_after = src[li].reset_after;
+    memcpy(p, src[li].bias, nb * 4); L.bias = p; p += nb;
+    memcpy(p, src[li].w, nw * 4); L.w = p; p += nw;
+    if (nr) { memcpy(p, src[li].rw, nr * 4); L.rw = p; p += nr; } else L.rw = NULL;
+  }
+  return m;
+}
+
+extern "C" pn_model *pn_model_from_rnnmodel(const RNNModel *r) {
+  if (!r) { pn_set_error("NULL RNNModel"); return NULL; }
+  LayerSrc s[PN_NLAYERS];
+  const DenseLayer *d[3] = {r->fc, r->fc_gb, r->fc_rb};
+  const int di[3] = {PN_L_FC, PN_L_FC_GB, PN_L_FC_RB};
+  for (int i = 0; i < 3; i++) s[di[i]] = {PN_KIND_DENSE, d[i]->nb_inputs, d[i]->nb_neurons, 1, d[i]->activation, 0, d[i]->bias, d[i]->input_weights, NULL};
+  const Conv1DLayer *c[2] = {r->conv1, r->conv2};
+  for (int i = 0; i < 2; i++) s[PN_L_CONV1 + i] = {PN_KIND_CONV1D, c[i]->nb_inputs, c[i]->nb_neurons, c[i]->kernel_size, c[i]->activation, 0, c[i]->bias, c[i]->input_weights, NULL};
+  const GRULayer *g[5] = {r->gru1, r->gru2, r->gru3, r->gru_gb, r->gru_rb};
+  for (int i = 0; i < 5; i++) s[PN_L_GRU1 + i] = {PN_KIND_GRU, g[i]->nb_inputs, g[i]->nb_neurons, 1, g[i]->activation, g[i]->reset_after, g[i]->bias, g[i]->input_weights, g[i]->recurrent_weights};
+  return model_from_sources(s);
+}
+
+extern "C" pn_model *pn_model_from_blob(const void *blob, size_t nbytes) {
+  const unsigned char *p = (const unsigned char *)blob;
+  if (!p || nbytes < 8 || memcmp(p, "PNW1", 4) != 0) { pn_set_error("not a PNW1 weight container"); return NULL; }
+  uint32_t n; memcpy(&n, p + 4, 4);
+  if (n != PN_NLAYERS) { pn_set_error("PNW1: %u layers, expected %d", n, PN_NLAYERS); return NULL; }
+  // arrays inside the blob are only 4-byte aligned relative to its start; copy through an
+  // aligned staging buffer
+  std::vector<float> stage((nbytes + 3) / 4);
+  LayerSrc s[PN_NLAYERS];
+  size_t off = 8, fo = 0;
+  for (uint32_t li = 0; li < n; li++) {
+    if (off + 24 > nbytes) { pn_set_error("PNW1: truncated"); return NULL; }
+    uint32_t h[6]; memcpy(h, p + off, 24); off += 24;
+    size_t nb, nw, nr;
+    size_t tot = layer_floats(h[0], h[1], h[2], h[3], &nb, &nw, &nr);
+    if (h[0] > 2 || off + tot * 4 > nbytes) { pn_set_error("PNW1: truncated or bad layer %u", li); return NULL; }
+    memcpy(&stage[fo], p + off, tot * 4); off += tot * 4;
+    s[li] = {(int)h[0], (int)h[1], (int)h[2], (int)h[3], (int)h[4], (int)h[5], &stage[fo], &stage[fo + nb], nr ? &stage[fo + nb + nw] : NULL};
+    fo += tot;
+  }
+  if (off != nbytes) { pn_set_error("PNW1: %zu trailing bytes", nbytes - off); return NULL; }
+  return model_from_sources(s);
+}
+
+extern "C" pn_model *pn_model_from_file(FILE *f) {
+  if (!f) { pn_set_error("NULL FILE"); return NULL; }
+  std::vector<unsigned char> buf;
+  unsigned char tmp[1 << 16];
+  size_t n;
+  while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  return pn_model_from_blob(buf.data(), buf.size());
+}
+
+extern "C" void pn_model_free(pn_model *m) { if (m) { free(m->storage); free(m); } }
+
+// ---- contexts -----------------------------------------------------------------------------------------
+enum { KF_FRONTEND, KF_FC, KF_CONV1, KF_CONV2, KF_GRU512, KF_GRU_RB, KF_FC_GB, KF_FC_RB, KF_BACKEND, KF_COUNT };
+static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2", "gru512", "gru_rb", "fc_gb", "fc_rb", "backend"};
+
+struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
+
+struct pn_ctx {
+  int device, B, nn_mode;
+  hipStream_t stream; bool own_stream;
+  int64_t t;                       // frames done
+  size_t bytes;
+  PnLayerHost geom[PN_NLAYERS];
+  DevLayer L[PN_NLAYERS];
+  PnTables *tables; float *tansig;
+  float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
+  float2 *Xs, *Ps;
+  int *last_period, *silence;
+  std::vector<void *> allocs;
+  bool profiling;
+  struct Ev { int fam; hipEvent_t a, b; };
+  std::vector<Ev> events;
+  double fam_ms[KF_COUNT]; int64_t fam_n[KF_COUNT];
+};
+
+static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
+  PN_HIP_CHECK(hipMalloc(p, bytes));
+  c->allocs.push_back(*p);
+  c->bytes += bytes;
+  if (zero) PN_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, c->stream));
+  return 0;
+}
+#define DEV_ALLOC(ptr, count, zero) \
+  do { if (dev_alloc(c, (void **)&(ptr), sizeof(*(ptr)) * (size_t)(count), zero)) goto fail; } while (0)
+
+static int upload(pn_ctx *c, float **dst, const float *src, size_t n) {
+  if (dev_alloc(c, (void **)dst, n * sizeof(float), false)) return -1;
+  PN_HIP_CHECK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+static int zero_state(pn_ctx *c) {
+  const size_t B = c->B;
+  PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->synth, 0, B * PN_FRAME * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->last_gain, 0, B * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->last_period, 0, B * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->silence, 0, B * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->feat, 0, B * PN_FEAT_STRIDE * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c1ring, 0, 5 * B * 128 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c2ring, 0, 3 * B * 512 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c2out, 0, B * 512 * 4, c->stream));
+  for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gru[i], 0, 2 * B * 512 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * B * 128 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->gr, 0, B * 68 * 4, c->stream));
+  c->t = 0;
+  return 0;
+}
+
+extern "C" void pn_ctx_destroy(pn_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (void *p : c->allocs) hipFree(p);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream) {
+  if (!model) { pn_set_error("NULL model"); return NULL; }
+  if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
+  if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    pn_set_error("no HIP device available (this library has no CPU fallback)");
+    return NULL;
+  }
+  if (device < 0 || device >= ndev) { pn_set_error("device %d out of range (%d devices)", device, ndev); return NULL; }
+  if (hipSetDevice(device) != hipSuccess) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
+  pn_ctx *c = new pn_ctx();
+  c->device = device; c->B = n_streams; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
+  memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
+  memset(c->L, 0, sizeof(c->L));
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { pn_set_error("hipStreamCreate failed"); delete c; return NULL; }
+    c->own_stream = true;
+  }
+  const size_t B = n_streams;
+  {
+    PnTables *ht = new PnTables();
+    pn_build_tables(ht);
+    int rc = dev_alloc(c, (void **)&c->tables, sizeof(PnTables), false);
+    if (!rc && hipMemcpyAsync(c->tables, ht, sizeof(PnTables), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1;
+    if (!rc) rc = upload(c, &c->tansig, ht->tansig, 208);
+    hipStreamSynchronize(c->stream);
+    delete ht;
+    if (rc) goto fail;
+  }
+  DEV_ALLOC(c->hist, B * PN_HIST, false);
+  DEV_ALLOC(c->synth, B * PN_FRAME, false);
+  DEV_ALLOC(c->last_gain, B, false);
+  DEV_ALLOC(c->last_period, B, false);
+  DEV_ALLOC(c->silence, B, false);
+  DEV_ALLOC(c->Xs, B * PN_SPEC_BINS, true);
+  DEV_ALLOC(c->Ps, B * PN_SPEC_BINS, true);
+  DEV_ALLOC(c->feat, B * PN_FEAT_STRIDE, false);
+  DEV_ALLOC(c->c1ring, 5 * B * 128, false);
+  DEV_ALLOC(c->c2ring, 3 * B * 512, false);
+  DEV_ALLOC(c->c2out, B * 512, false);
+  for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * B * 512, false);
+  DEV_ALLOC(c->rb, 2 * B * 128, false);
+  DEV_ALLOC(c->gr, B * 68, false);
+  DEV_ALLOC(c->io_in, B * PN_FRAME, false);
+  DEV_ALLOC(c->io_out, B * PN_FRAME, false);
+  if (zero_state(c)) goto fail;
+  for (int li = 0; li < PN_NLAYERS; li++) {
+    const PnLayerHost &H = model->L[li];
+    c->geom[li] = H; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL;
+    size_t nb, nw, nr;
+    layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
+    if (upload(c, &c->L[li].bias, H.bias, nb)) goto fail;
+    if (nn_mode == PN_NN_STRICT) {
+      if (upload(c, &c->L[li].w, H.w, nw)) goto fail;
+      if (nr && upload(c, &c->L[li].rw, H.rw, nr)) goto fail;
+    } else {
+      const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
+      const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
+      std::vector<float> packed(pn_packed_floats(K, ncols, ctr));
+      pn_pack_weights(H.w, K, ncols, ctr, packed.data());
+      if (upload(c, &c->L[li].wp, packed.data(), packed.size())) goto fail;
+      if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
+      if (nr) {
+        std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
+        pn_pack_weights(H.rw, H.nn, ncols, 1, rp.data());
+        if (upload(c, &c->L[li].rwp, rp.data(), rp.size())) goto fail;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+      }
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
+  return c;
+fail:
+  pn_ctx_destroy(c);
+  return NULL;
+}
+
+extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; hipSetDevice(c->device); return zero_state(c); }
+extern "C" int pn_ctx_n_streams(const pn_ctx *c) { return c ? c->B : -1; }
+extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
+extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
+extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
+
+// ---- profiling ------------------------------------------------------------------------------------------
+struct Scope {
+  pn_ctx *c; int fam; hipEvent_t a, b; bool on;
+  Scope(pn_ctx *c_, int fam_) : c(c_), fam(fam_), on(c_->profiling) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+  }
+  ~Scope() { if (on) { hipEventRecord(b, c->stream); c->events.push_back({fam, a, b}); } }
+};
+
+static int flush_events(pn_ctx *c) {
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (auto &e : c->events) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->fam_ms[e.fam] += ms; c->fam_n[e.fam]++; }
+    hipEventDestroy(e.a); hipEventDestroy(e.b);
+  }
+  c->events.clear();
+  return 0;
+}
+
+extern "C" int pn_ctx_set_profiling(pn_ctx *c, int enable) { if (!c) return -1; c->profiling = enable != 0; return 0; }
+extern "C" int pn_kernel_count(void) { return KF_COUNT; }
+extern "C" const char *pn_kernel_name(int i) { return (i >= 0 && i < KF_COUNT) ? kKernelNames[i] : NULL; }
+extern "C" int pn_ctx_kernel_time(pn_ctx *c, const char *name, double *total_ms, int64_t *launches) {
+  if (!c || !name) return -1;
+  if (flush_events(c)) return -1;
+  for (int i = 0; i < KF_COUNT; i++)
+    if (!strcmp(name, kKernelNames[i])) { if (total_ms) *total_ms = c->fam_ms[i]; if (launches) *launches = c->fam_n[i]; return 0; }
+  pn_set_error("unknown kernel family '%s'", name);
+  return -1;
+}
+extern "C" int pn_ctx_reset_profile(pn_ctx *c) {
+  if (!c) return -1;
+  if (flush_events(c)) return -1;
+  memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
+  return 0;
+}
+
+// ---- the per-frame launch sequence -----------------------------------------------------------------------
+static PnSegs seg1(const float *p, int ld, int width) { PnSegs s; memset(&s, 0, sizeof(s)); s.p[0] = p; s.ld[0] = ld; s.width[0] = width; s.n = 1; return s; }
+
+// compute_rnn (rnn.cpp:42-81) for all streams; features in c->feat, result in c->gr
+static void launch_rnn(pn_ctx *c) {
+  const size_t B = c->B; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
+  hipStream_t st = c->stream; const float *tab = c->tansig;
+  const int cur = (int)(t & 1), nxt = cur ^ 1;
+  float *c1new = c->c1ring + (size_t)(t % 5) * B * 128;
+  float *c2new = c->c2ring + (size_t)(t % 3) * B * 512;
+  { Scope sc(c, KF_FC);
+    PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, PN_NFEAT);
+    pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B); }
+  { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
+    PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
+    for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * B * 128; A.ld[j] = 128; A.width[j] = 128; }
+    pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B); }
+  { Scope sc(c, KF_CONV2);
+    PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
+    for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * B * 512; A.ld[j] = 512; A.width[j] = 512; }
+    pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B); }
+  const float *x = c->c2out;
+  for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
+    Scope sc(c, KF_GRU512);
+    const int li = PN_L_GRU1 + i;
+    float *ho = c->gru[i] + (size_t)cur * B * 512, *hn = c->gru[i] + (size_t)nxt * B * 512;
+    PnSegs X = seg1(x, 512, 512);
+    pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
+    x = hn;
+  }
+  const float *g1 = c->gru[0] + (size_t)nxt * B * 512, *g2 = c->gru[1] + (size_t)nxt * B * 512,
+              *g3 = c->gru[2] + (size_t)nxt * B * 512, *gb = c->gru[3] + (size_t)nxt * B * 512;
+  float *rbo = c->rb + (size_t)cur * B * 128, *rbn = c->rb + (size_t)nxt * B * 128;
+  { Scope sc(c, KF_GRU_RB);   // input = [gru3 | conv2 out] (rnn.cpp:67-69)
+    PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
+    X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
+    const int li = PN_L_GRU_RB;
+    pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B); }
+  { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
+    PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
+    const float *ps[5] = {c->c2out, g1, g2, g3, gb};
+    for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
+    pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B); }
+  { Scope sc(c, KF_FC_RB);
+    PnSegs A = seg1(rbn, 128, 128);
+    pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B); }
+}
+
+static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16) {
+  if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  { Scope sc(c, KF_FRONTEND);
+    pn_launch_frontend(c->stream, c->tables, c->B, (int)(c->t % PN_HIST_FRAMES), d_in, is_i16, c->hist, c->Xs, c->Ps,
+                       c->feat, c->silence, c->last_period, c->last_gain); }
+  launch_rnn(c);
+  { Scope sc(c, KF_BACKEND);
+    pn_launch_backend(c->stream, c->tables, c->B, c->Xs, c->Ps, c->gr, c->silence, c->synth, d_out, is_i16); }
+  if (d_gr) PN_HIP_CHECK(hipMemcpyAsync(d_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToDevice, c->stream));
+  PN_HIP_CHECK(hipGetLastError());
+  c->t++;
+  return 0;
+}
+
+extern "C" int pn_process_f32(pn_ctx *c, const float *d_in, float *d_out, float *d_gr) { return process_dev(c, d_in, d_out, d_gr, 0); }
+extern "C" int pn_process_i16(pn_ctx *c, const int16_t *d_in, int16_t *d_out, float *d_gr) { return process_dev(c, d_in, d_out, d_gr, 1); }
+extern "C" int pn_process_i16_multi(pn_ctx *c, const int16_t *d_in, int16_t *d_out, float *d_gr, int n_frames) {
+  if (!c) return -1;
+  const size_t fs = (size_t)c->B * PN_FRAME;
+  for (int f = 0; f < n_frames; f++)
+    if (process_dev(c, d_in + f * fs, d_out + f * fs, d_gr ? d_gr + (size_t)f * c->B * 68 : NULL, 1)) return -1;
+  return 0;
+}
+
+static int process_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
+  if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  const size_t nbytes = (size_t)c->B * PN_FRAME * (is_i16 ? 2 : 4);
+  PN_HIP_CHECK(hipMemcpyAsync(c->io_in, h_in, nbytes, hipMemcpyHostToDevice, c->stream));
+  if (process_dev(c, c->io_in, c->io_out, NULL, is_i16)) return -1;
+  PN_HIP_CHECK(hipMemcpyAsync(h_out, c->io_out, nbytes, hipMemcpyDeviceToHost, c->stream));
+  if (h_gr) PN_HIP_CHECK(hipMemcpyAsync(h_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToHost, c->stream));
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int pn_process_host_f32(pn_ctx *c, const float *h_in, float *h_out, float *h_gr) { return process_host(c, h_in, h_out, h_gr, 0); }
+extern "C" int pn_process_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return process_host(c, h_in, h_out, h_gr, 1); }
+
+extern "C" int pn_ctx_read_features(pn_ctx *c, float *h_feat, int32_t *h_silence) {
+  if (!c) return -1;
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  if (h_feat)
+    PN_HIP_CHECK(hipMemcpy2DAsync(h_feat, PN_NFEAT * 4, c->feat, PN_FEAT_STRIDE * 4, PN_NFEAT * 4, c->B, hipMemcpyDeviceToHost, c->stream));
+  if (h_silence) PN_HIP_CHECK(hipMemcpyAsync(h_silence, c->silence, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_gr) {
+  if (!c || !h_feat || !h_gr) { pn_set_error("NULL argument"); return -1; }
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_HIP_CHECK(hipMemcpy2DAsync(c->feat, PN_FEAT_STRIDE * 4, h_feat, PN_NFEAT * 4, PN_NFEAT * 4, c->B, hipMemcpyHostToDevice, c->stream));
+  launch_rnn(c);
+  PN_HIP_CHECK(hipMemcpyAsync(h_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToHost, c->stream));
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PN_HIP_CHECK(hipGetLastError());
+  c->t++;
+  return 0;
+}

@@ -1,0 +1,51 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/percepnet_hip.h declares, plus the reference's Itanium-mangled rnnoise_* names
+(reference src/rnnoise.h:49-68 compiled as C++).  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from percepnet_amd import api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return ctypes.CDLL(api.LIB_PATH)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "percepnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b((?:pn_|rnnoise_)\w+)\s*\(", hdr))
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/percepnet_hip.h but not exported"
+
+
+def test_reference_mangled_symbols_exported(lib):
+    for n in ["_Z16rnnoise_get_sizev", "_Z12rnnoise_initP12DenoiseStateP8RNNModel",
+              "_Z14rnnoise_createP8RNNModel", "_Z15rnnoise_destroyP12DenoiseState",
+              "_Z21rnnoise_process_frameP12DenoiseStatePfPKfP8_IO_FILE",
+              "_Z23rnnoise_model_from_fileP8_IO_FILE", "_Z18rnnoise_model_freeP8RNNModel"]:
+        assert hasattr(lib, n), n
+
+
+def test_model_parsing_and_error_paths_without_gpu(lib, blob):
+    L = api.load_library()
+    assert L.pn_model_from_blob(b"nope", 4) is None
+    assert b"PNW1" in L.pn_last_error()
+    m = api.Model(blob)
+    assert m.h
+    bad = bytearray(blob); bad[8] = 7  # first layer kind -> invalid
+    assert L.pn_model_from_blob(bytes(bad), len(bad)) is None
+    import torch
+    if not torch.cuda.is_available():
+        # the product path must fail loudly without a GPU — never fall back to a CPU path
+        with pytest.raises(api.PercepNetError):
+            api.Context(m, 4)
+    m.close()

@@ -1,0 +1,249 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU
+oracle on identical seeded inputs, against the committed golden vectors, and — at full batch
+sizes — through size-independent properties.
+
+Tolerances (BASELINE.json north_star):
+  * STRICT network mode: bit-exact PCM, g/r tap and features (integer/bit equality).
+  * MFMA network mode (fused multiply-add chain instead of mul+add): PCM within +-1 LSB per sample,
+    g/r within 2e-5 absolute; features (network-independent) still bit-exact.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from percepnet_amd import api, synth, weights
+
+pytestmark = pytest.mark.gpu
+
+PCM_TOL_LSB = 1
+GR_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    m = api.Model(blob)
+    yield m
+    m.close()
+
+
+def _oracle_batch(oracle, pcm):
+    outs, grs = [], []
+    for s in range(pcm.shape[0]):
+        o, g = oracle.run_pcm(pcm[s])
+        outs.append(o); grs.append(g)
+    return np.stack(outs), np.stack(grs)
+
+
+def test_strict_mode_bit_exact_pcm_and_taps(model, oracle):
+    """8 streams incl. the burst/silence stream (7), 40 frames: everything bit-identical."""
+    B, T = 8, 40
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, pcm)
+    assert np.array_equal(out, ro)
+    assert np.array_equal(gr, rg)
+    ctx.close()
+
+
+def test_golden_vectors_strict(model, golden_dir):
+    """The committed outputs of the compiled reference (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
+    pcm = np.stack([g["in_0"], g["in_7"], g["in_13"]])
+    ctx = api.Context(model, 3, nn_mode=api.NN_STRICT)
+    out, gr = ctx.run_pcm(pcm)
+    for i, s in enumerate((0, 7, 13)):
+        assert np.array_equal(out[i], g[f"out_{s}"]), s
+        assert np.array_equal(gr[i], g[f"gr_{s}"]), s
+    ctx.close()
+    # float in / float out convention of rnnoise_process_frame
+    ctx = api.Context(model, 1, nn_mode=api.NN_STRICT)
+    x = g["fin_0"].reshape(-1, 480)
+    y = np.concatenate([ctx.process_f32(x[t])[0][0] for t in range(x.shape[0])])
+    assert np.array_equal(y, g["fout_0"])
+    ctx.close()
+
+
+def test_golden_vectors_mfma(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
+    pcm = np.stack([g["in_0"], g["in_7"], g["in_13"]])
+    ctx = api.Context(model, 3, nn_mode=api.NN_MFMA)
+    out, gr = ctx.run_pcm(pcm)
+    for i, s in enumerate((0, 7, 13)):
+        d = np.abs(out[i].astype(np.int32) - g[f"out_{s}"].astype(np.int32)).max()
+        assert d <= PCM_TOL_LSB, (s, d)
+        assert np.abs(gr[i] - g[f"gr_{s}"]).max() <= GR_TOL
+    ctx.close()
+
+
+def test_features_and_silence_bit_exact(model, oracle):
+    """DSP front end alone: the 70 features and the silence decision never depend on the network
+    and must match bit for bit in either mode (stream 7 has digital silence, 13 pitch ambiguity)."""
+    streams = [0, 3, 7, 13, 27, 33]
+    T = 60
+    pcm = np.stack([synth.synth_stream(s, T) for s in streams])
+    ctx = api.Context(model, len(streams), nn_mode=api.NN_MFMA)
+    feats = np.zeros((len(streams), T, 70), np.float32)
+    sils = np.zeros((len(streams), T), np.int32)
+    for t in range(T):
+        ctx.process_i16(pcm[:, t * 480:(t + 1) * 480], want_gr=False)
+        feats[:, t], sils[:, t] = ctx.read_features()
+    for i, s in enumerate(streams):
+        rf, rs = oracle.features(pcm[i].astype(np.float32) / np.float32(32768))
+        assert np.array_equal(feats[i], rf), s
+        assert np.array_equal(sils[i], rs), s
+    assert sils[2].any() and not sils[0].all()   # the silence branch really was exercised
+    ctx.close()
+
+
+def test_mfma_mode_within_one_lsb(model, oracle):
+    """configs[1]-style batch slice: 40 streams x 100 frames (1 s of audio each)."""
+    B, T = 40, 100
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, pcm)
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    assert d.max() <= PCM_TOL_LSB, d.max()
+    assert np.abs(gr - rg).max() <= GR_TOL, np.abs(gr - rg).max()
+    ctx.close()
+
+
+def test_network_alone_random_features(model, oracle):
+    """compute_rnn on random features with carried state, 25 steps; strict exact, MFMA 2e-5."""
+    B, T = 5, 25
+    rng = np.random.default_rng(11)
+    feats = (rng.standard_normal((T, B, 70)) * 0.7).astype(np.float32)
+    ref = np.zeros((T, B, 68), np.float32)
+    for b in range(B):
+        st = oracle.lib.pno_create(oracle.model)
+        for t in range(T):
+            g = np.zeros(34, np.float32); r = np.zeros(34, np.float32)
+            f = np.ascontiguousarray(feats[t, b])
+            oracle.lib.pno_compute_rnn(st, g.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       f.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+            ref[t, b, :34] = g; ref[t, b, 34:] = r
+        oracle.lib.pno_destroy(st)
+    for mode, tol in ((api.NN_STRICT, 0.0), (api.NN_MFMA, GR_TOL)):
+        ctx = api.Context(model, B, nn_mode=mode)
+        got = np.stack([ctx.compute_rnn(feats[t]) for t in range(T)])
+        assert np.abs(got - ref).max() <= tol, (mode, np.abs(got - ref).max())
+        ctx.close()
+
+
+def test_saturating_weights_table_clamp(oracle):
+    """Weights scaled x6 drive the tanh table index into its clamp (vec.h:62-63)."""
+    from oracle.oracle import Oracle
+    sat = weights.pack_blob(weights.random_layers(3, scale=6.0))
+    o2 = Oracle(sat)
+    m2 = api.Model(sat)
+    pcm = synth.synth_batch(3, 30, first_stream=4)
+    ctx = api.Context(m2, 3, nn_mode=api.NN_STRICT)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(o2, pcm)
+    assert np.array_equal(out, ro) and np.array_equal(gr, rg)
+    assert rg.min() < 0.02 and rg.max() > 0.98
+    ctx.close(); m2.close()
+
+
+@pytest.mark.parametrize("B", [1, 129, 300])
+def test_ragged_batch_sizes(model, oracle, B):
+    """Batches that do not fill the 128-row GEMM tiles / the DSP grid: 1, 129, 300 streams."""
+    T = 8
+    base = synth.synth_batch(6, T)
+    pcm = base[np.arange(B) % 6]
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, base)
+    for s in range(B):
+        assert np.abs(out[s].astype(np.int32) - ro[s % 6].astype(np.int32)).max() <= PCM_TOL_LSB
+        assert np.abs(gr[s] - rg[s % 6]).max() <= GR_TOL
+    ctx.close()
+
+
+def test_zero_input_gives_zero_output_and_reset(model):
+    B = 4
+    ctx = api.Context(model, B)
+    z = np.zeros((B, 480), np.int16)
+    for _ in range(8):
+        out, gr = ctx.process_i16(z)
+        assert not out.any()
+    _, sil = ctx.read_features()
+    assert sil.all()
+    pcm = synth.synth_batch(B, 6)
+    a, _ = ctx.run_pcm(pcm)
+    ctx.reset()
+    b, _ = ctx.run_pcm(pcm)       # reset() restores the all-zero initial state
+    ctx2 = api.Context(model, B)
+    c, _ = ctx2.run_pcm(pcm)
+    assert np.array_equal(b, c)
+    ctx.close(); ctx2.close()
+
+
+def test_full_size_properties_65536_streams(model, oracle):
+    """BASELINE configs[2] size.  Properties that do not need the oracle at full size: streams are
+    independent and tile/XCD placement never changes a result (identical input => bit-identical
+    output wherever the stream sits), plus an oracle check on the 16 distinct inputs."""
+    import torch
+    B, T, P = 65536, 3, 16
+    base = synth.synth_batch(P, T)
+    idx = np.arange(B) % P
+    dev = torch.device("cuda:0")
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for t in range(T):
+        fr = torch.from_numpy(base[:, t * 480:(t + 1) * 480][idx]).to(dev)
+        o = torch.empty_like(fr)
+        g = torch.empty((B, 68), dtype=torch.float32, device=dev)
+        ctx.process_i16_dev(fr.data_ptr(), o.data_ptr(), g.data_ptr())
+        torch.cuda.synchronize()
+        o = o.cpu().numpy(); g = g.cpu().numpy()
+        assert np.array_equal(o, o[:P][idx]), "identical streams diverged across tiles"
+        assert np.array_equal(g, g[:P][idx])
+        outs.append((o[:P], g[:P]))
+    ro, rg = _oracle_batch(oracle, base)
+    for t in range(1, T):
+        d = np.abs(outs[t][0].astype(np.int32) - ro[:, (t - 1) * 480:t * 480].astype(np.int32)).max()
+        assert d <= PCM_TOL_LSB
+        assert np.abs(outs[t][1] - rg[:, t]).max() <= GR_TOL
+    ctx.close()
+
+
+def test_rnnoise_drop_in_symbols(blob, oracle, tmp_path):
+    """The reference's own entry points (mangled C++ names of rnnoise.h:49-68), used the way
+    main.cpp:30-39 uses them, with the model loaded through rnnoise_model_from_file."""
+    L = ctypes.CDLL(api.LIB_PATH)
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    path = tmp_path / "model.pnw"
+    path.write_bytes(blob)
+    f = libc.fopen(str(path).encode(), b"rb")
+    mff = getattr(L, "_Z23rnnoise_model_from_fileP8_IO_FILE"); mff.restype = ctypes.c_void_p; mff.argtypes = [ctypes.c_void_p]
+    rm = mff(f); libc.fclose(f)
+    assert rm
+    create = getattr(L, "_Z14rnnoise_createP8RNNModel"); create.restype = ctypes.c_void_p; create.argtypes = [ctypes.c_void_p]
+    proc = getattr(L, "_Z21rnnoise_process_frameP12DenoiseStatePfPKfP8_IO_FILE")
+    proc.restype = ctypes.c_float; proc.argtypes = [ctypes.c_void_p] * 4
+    destroy = getattr(L, "_Z15rnnoise_destroyP12DenoiseState"); destroy.argtypes = [ctypes.c_void_p]
+    st = create(rm)
+    assert st
+    tap = tmp_path / "feature_test.raw"
+    ff = libc.fopen(str(tap).encode(), b"wb")
+    pcm = synth.synth_stream(0, 10)
+    outs = []
+    for t in range(10):
+        x = (pcm[t * 480:(t + 1) * 480].astype(np.float32) / np.float32(32768)).copy()
+        assert proc(st, x.ctypes.data, x.ctypes.data, ff) == 0.0      # in-place, like main.cpp:35
+        outs.append((x * 32768).astype(np.int32).astype(np.int16))
+    libc.fclose(ff); destroy(st)
+    getattr(L, "_Z18rnnoise_model_freeP8RNNModel")(ctypes.c_void_p(rm))
+    ro, rg = oracle.run_pcm(pcm)
+    got = np.concatenate(outs[1:])
+    assert np.abs(got.astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+    tapdata = np.fromfile(tap, np.float32).reshape(10, 68)
+    assert np.abs(tapdata - rg).max() <= GR_TOL
