@@ -2,9 +2,10 @@
 
 The reference's two sample PCMs are absent (.MISSING_LARGE_BLOBS), so every parity and bench
 input is generated: stream ``s`` is a gated harmonic source with vibrato plus white noise;
-5 % of the streams are noise bursts with 1 s silences (exercises the ``silence`` branch,
-denoise.cpp:433,536) and 5 % are 200+300 Hz two-tone (pitch ambiguity for
-remove_doubling, pitch.cpp:424).  Values are int16 PCM, the CLI's format (main.cpp:30-34).
+5 % of the streams are noise bursts with 1 s silences, 5 % are 200+300 Hz two-tone (pitch
+ambiguity for remove_doubling, pitch.cpp:424) and 5 % are near-full-scale ("loud": the only
+frames for which the reference's ``silence = sum(Ex) < 0.1`` test, denoise.cpp:433, is false, so
+the only ones that exercise the pitch-filter branch, 536-538).  Values are int16 PCM, the CLI's format (main.cpp:30-34).
 """
 import numpy as np
 
@@ -19,6 +20,8 @@ def stream_kind(s):
         return "bursts"
     if m == 13:
         return "twotone"
+    if m == 3:
+        return "loud"
     return "voiced"
 
 
@@ -41,6 +44,17 @@ def synth_stream(s, n_frames, base_seed=BASE_SEED):
         for k in range(1, 12):
             x += (0.5 / k) * np.sin(k * phi)
         x = a * v * x + ns * noise
+    elif kind == "loud":
+        # near-full-scale (clipping) voiced source: with the reference's 1/960 FFT scale and
+        # int16/32768 input, only frames this loud make sum(Ex) >= 0.1, i.e. take the NON-silent
+        # branch that applies the pitch filter (denoise.cpp:433,536-538)
+        f0 = F + 30.0 * np.sin(2 * np.pi * 0.7 * t)
+        phi = 2 * np.pi * np.cumsum(f0) / FS
+        v = ((t * 1.3 + ph) % 1.0 < 0.6).astype(np.float64)
+        x = np.zeros(n)
+        for k in range(1, 12):
+            x += (0.5 / k) * np.sin(k * phi)
+        x = 2.5 * v * x + 0.25 * noise
     elif kind == "bursts":
         gate = (((t + ph) % 2.0) < 1.0).astype(np.float64)  # 1 s noise, 1 s digital silence
         x = (a * 0.5) * gate * noise

@@ -13,8 +13,9 @@ Produces
   tables.npz              tansig_table.h values, FFT twiddles/bitrev/factors from the compiled
                           reference (oracle/_ref).
   pcm_golden.npz          int16 PCM in / PCM out / g,r tap of the compiled reference
-                          (percepNet_run semantics) for streams 0 (voiced), 7 (bursts+silence),
-                          13 (two-tone), 48 frames each, plus float-in/float-out of stream 0.
+                          (percepNet_run semantics) for streams 0 (voiced), 3 (loud: non-silent
+                          frames), 7 (bursts+silence), 13 (two-tone), 48 frames each, plus
+                          float-in/float-out of stream 0 and of stream 3 at int16 scale.
 """
 import ctypes
 import hashlib
@@ -92,13 +93,18 @@ def main():
     np.savez_compressed(os.path.join(HERE, "tables.npz"), twiddles=tw, bitrev=br, factors=fac[:10], tansig=tansig)
 
     g = {}
-    for s in (0, 7, 13):
+    for s in (0, 3, 7, 13):
         pcm = synth.synth_stream(s, 48)
         out, gr = ref.run_pcm(pcm)
         g[f"in_{s}"] = pcm; g[f"out_{s}"] = out; g[f"gr_{s}"] = gr
     x = synth.synth_stream(0, 48).astype(np.float32) / np.float32(32768)
     fo, fgr = ref.run_float(x)
     g["fin_0"] = x; g["fout_0"] = fo
+    # original-RNNoise sample convention (floats at int16 scale, no /32768): every frame is
+    # "non-silent", exercising the pitch-filter branch at a very different numeric range
+    x3 = synth.synth_stream(3, 48).astype(np.float32)
+    fo3, fgr3 = ref.run_float(x3)
+    g["fin_3"] = x3; g["fout_3"] = fo3; g["fgr_3"] = fgr3
     np.savez_compressed(os.path.join(HERE, "pcm_golden.npz"), **g)
     print("golden written")
 

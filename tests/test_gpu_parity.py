@@ -51,10 +51,10 @@ def test_strict_mode_bit_exact_pcm_and_taps(model, oracle):
 def test_golden_vectors_strict(model, golden_dir):
     """The committed outputs of the compiled reference (tests/golden/make_golden.py)."""
     g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
-    pcm = np.stack([g["in_0"], g["in_7"], g["in_13"]])
-    ctx = api.Context(model, 3, nn_mode=api.NN_STRICT)
+    pcm = np.stack([g["in_0"], g["in_3"], g["in_7"], g["in_13"]])
+    ctx = api.Context(model, 4, nn_mode=api.NN_STRICT)
     out, gr = ctx.run_pcm(pcm)
-    for i, s in enumerate((0, 7, 13)):
+    for i, s in enumerate((0, 3, 7, 13)):
         assert np.array_equal(out[i], g[f"out_{s}"]), s
         assert np.array_equal(gr[i], g[f"gr_{s}"]), s
     ctx.close()
@@ -63,15 +63,21 @@ def test_golden_vectors_strict(model, golden_dir):
     x = g["fin_0"].reshape(-1, 480)
     y = np.concatenate([ctx.process_f32(x[t])[0][0] for t in range(x.shape[0])])
     assert np.array_equal(y, g["fout_0"])
+    ctx.reset()
+    # int16-scale floats (the original RNNoise convention): all frames non-silent
+    x = g["fin_3"].reshape(-1, 480)
+    res = [ctx.process_f32(x[t]) for t in range(x.shape[0])]
+    assert np.array_equal(np.concatenate([r[0][0] for r in res]), g["fout_3"])
+    assert np.array_equal(np.stack([r[1][0] for r in res]), g["fgr_3"])
     ctx.close()
 
 
 def test_golden_vectors_mfma(model, golden_dir):
     g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
-    pcm = np.stack([g["in_0"], g["in_7"], g["in_13"]])
-    ctx = api.Context(model, 3, nn_mode=api.NN_MFMA)
+    pcm = np.stack([g["in_0"], g["in_3"], g["in_7"], g["in_13"]])
+    ctx = api.Context(model, 4, nn_mode=api.NN_MFMA)
     out, gr = ctx.run_pcm(pcm)
-    for i, s in enumerate((0, 7, 13)):
+    for i, s in enumerate((0, 3, 7, 13)):
         d = np.abs(out[i].astype(np.int32) - g[f"out_{s}"].astype(np.int32)).max()
         assert d <= PCM_TOL_LSB, (s, d)
         assert np.abs(gr[i] - g[f"gr_{s}"]).max() <= GR_TOL
@@ -80,7 +86,8 @@ def test_golden_vectors_mfma(model, golden_dir):
 
 def test_features_and_silence_bit_exact(model, oracle):
     """DSP front end alone: the 70 features and the silence decision never depend on the network
-    and must match bit for bit in either mode (stream 7 has digital silence, 13 pitch ambiguity)."""
+    and must match bit for bit in either mode (stream 3 is loud enough to be non-silent, 7 has
+    digital silence, 13 pitch ambiguity)."""
     streams = [0, 3, 7, 13, 27, 33]
     T = 60
     pcm = np.stack([synth.synth_stream(s, T) for s in streams])
@@ -94,7 +101,7 @@ def test_features_and_silence_bit_exact(model, oracle):
         rf, rs = oracle.features(pcm[i].astype(np.float32) / np.float32(32768))
         assert np.array_equal(feats[i], rf), s
         assert np.array_equal(sils[i], rs), s
-    assert sils[2].any() and not sils[0].all()   # the silence branch really was exercised
+    assert 0 < sils[1].sum() < T and sils[2].all()   # both branches of `silence` were exercised
     ctx.close()
 
 

@@ -57,13 +57,19 @@ def test_nnet_known_answers(oracle, golden_dir):
 
 def test_oracle_matches_golden_pcm(oracle, golden_dir):
     g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))
-    for s in (0, 7, 13):
+    for s in (0, 3, 7, 13):
         assert np.array_equal(synth.synth_stream(s, 48), g[f"in_{s}"]), "synthetic generator drifted"
         out, gr = oracle.run_pcm(g[f"in_{s}"])
         assert np.array_equal(out, g[f"out_{s}"])
         assert np.array_equal(gr.view(np.uint32), g[f"gr_{s}"].view(np.uint32))
     fo, _ = oracle.run_float(g["fin_0"])
     assert np.array_equal(fo.view(np.uint32), g["fout_0"].view(np.uint32))
+    fo, fgr = oracle.run_float(g["fin_3"])
+    assert np.array_equal(fo.view(np.uint32), g["fout_3"].view(np.uint32))
+    assert np.array_equal(fgr.view(np.uint32), g["fgr_3"].view(np.uint32))
+    # the loud stream really takes both branches of `if(!silence)` (denoise.cpp:536)
+    _, sil = oracle.features(g["in_3"].astype(np.float32) / np.float32(32768))
+    assert 0 < sil.sum() < sil.size
 
 
 def test_activation_table_edges(oracle):
@@ -79,7 +85,7 @@ def test_activation_table_edges(oracle):
 @pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no /root/reference)")
 def test_oracle_bit_exact_vs_compiled_reference(blob, oracle):
     ref = Reference(blob)
-    for s in (1, 27, 33, 47):  # voiced, bursts, two-tone, voiced — not the golden streams
+    for s in (1, 23, 27, 33, 43):  # voiced, loud, bursts, two-tone, loud — not the golden streams
         pcm = synth.synth_stream(s, 120)
         a, ga = oracle.run_pcm(pcm)
         b, gb = ref.run_pcm(pcm)

@@ -8,7 +8,7 @@ from oracle.oracle import Oracle
 blob = weights.default_blob(1234)
 orc = Oracle(blob)
 model = api.Model(blob)
-streams = [0, 7, 13, 21]
+streams = [0, 3, 7, 13, 23]
 T = 30
 pcm = np.stack([synth.synth_stream(s, T) for s in streams])
 B = len(streams)
