@@ -27,10 +27,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PERCEPNET_LIB", LIB_PATH)   # override: tuning variants (build.build_variant)
+    if not os.path.exists(path):
         raise PercepNetError(
-            f"{LIB_PATH} is missing: build it with `python -m percepnet_amd.build` (no CPU fallback exists)")
-    L = ctypes.CDLL(LIB_PATH)
+            f"{path} is missing: build it with `python -m percepnet_amd.build` (no CPU fallback exists)")
+    L = ctypes.CDLL(path)
     L.pn_last_error.restype = ctypes.c_char_p
     L.pn_version.restype = ctypes.c_char_p
     L.pn_model_from_blob.restype = _vp

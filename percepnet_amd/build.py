@@ -37,6 +37,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines, verbose=False):
+    """Tuning aid: build lib/variants/<name>/libpercepnet_hip.so with extra -D flags
+    (select it at run time with PERCEPNET_LIB=<path>)."""
+    vdir = os.path.join(LIBDIR, "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(vdir, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + list(defines) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
+              ["-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    lib = os.path.join(vdir, "libpercepnet_hip.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()

@@ -16,38 +16,62 @@
 // synthesis are bit-identical to the CPU reference given identical g/r.  Data-parallel work
 // (butterflies of one FFT stage, bins, lags) is spread over lanes; every order-sensitive
 // reduction (inner products, running energies, band sums, Levinson) runs as the reference's
-// sequential chain on one lane — one lane per lag/band, never a shuffle tree.
+// sequential chain on one lane — one lane per lag/band, never a shuffle tree.  Only the ADDs of
+// such a chain are serially dependent: operands are fetched from LDS 16 at a time and the
+// products formed ahead of the chain.
 //
-// Work distribution: blocks are a single wavefront (so __syncthreads() is a wave-local LDS
-// fence); a block stages the shared read-only tables (twiddles, window, digit-reversal, band
-// map: 13.6 KB) into LDS once and then loops over streams  s = blockIdx.x, += gridDim.x.
+// Work distribution: 512-thread blocks = 8 wavefronts = 8 concurrent streams.  The block stages
+// the shared read-only tables (twiddles, window, digit-reversal, band map: 13.6 KB) into LDS
+// once; each wavefront owns a private 8.3 KB LDS slice (FFT buffer, aliased by the pitch scratch)
+// and loops over streams  s = blockIdx.x*8 + wave, += gridDim.x*8.  After the table staging no
+// block-level barrier exists: a wavefront only ever synchronises with itself (LDS operations of
+// one wave execute in order; PN_WAVE_SYNC is the compiler-level fence), so the 16 waves a CU
+// holds (2 blocks, 80 KB LDS each) drift freely and hide each other's chain latency.
 #include "pn_common.h"
 
 #define LANES 64
+#ifndef PN_DSP_WPB
+#define PN_DSP_WPB 8          // wavefronts (= concurrent streams) per block
+#endif
+#ifndef PN_DSP_WAVES_PER_SIMD
+#define PN_DSP_WAVES_PER_SIMD 4
+#endif
+#define WPB PN_DSP_WPB
+#define DSP_THREADS (LANES * WPB)
 
-struct PnDspShared {
+// same-wave LDS producer -> consumer ordering
+#define PN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// same-wave global-memory store -> load ordering (drains vmcnt)
+#define PN_WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct PnDspTablesLds {
   float2 tw[PN_NFFT];            // 7680 B
-  float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch aliases it
-  float2 X[PN_SPEC_BINS];        // 3200 B  spectrum of the frame being enhanced
   float win[PN_FRAME];           // 1920 B
   float frac[PN_SPEC_BINS];      // 1600 B
   int16_t bitrev[PN_NFFT];       // 1920 B
   int16_t border[PN_NB + 2];
   uint8_t band[PN_SPEC_BINS];
-  float e[4][PN_NB + 2];         // Ex, Ep, Exp, gains scratch
   float comb_w[8];
 };
+struct PnDspWaveLds {
+  float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
+  float e[4][PN_NB + 2];
+};
+struct PnDspShared {
+  PnDspTablesLds t;
+  PnDspWaveLds w[WPB];
+};
 
-__device__ __forceinline__ void pn_stage_tables(PnDspShared &S, const PnTables *__restrict__ T) {
-  const int lane = threadIdx.x;
-  for (int i = lane; i < PN_NFFT; i += LANES) {
+__device__ __forceinline__ void pn_stage_tables(PnDspTablesLds &S, const PnTables *__restrict__ T) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < PN_NFFT; i += DSP_THREADS) {
     S.tw[i] = make_float2(T->tw[2 * i], T->tw[2 * i + 1]);
     S.bitrev[i] = T->bitrev[i];
   }
-  for (int i = lane; i < PN_FRAME; i += LANES) S.win[i] = T->half_window[i];
-  for (int i = lane; i < PN_SPEC_BINS; i += LANES) { S.frac[i] = T->bin_frac[i]; S.band[i] = T->bin_band[i]; }
-  if (lane < PN_NB + 2) S.border[lane] = T->border[lane];
-  if (lane < 8) S.comb_w[lane] = T->comb_hann[lane];
+  for (int i = tid; i < PN_FRAME; i += DSP_THREADS) S.win[i] = T->half_window[i];
+  for (int i = tid; i < PN_SPEC_BINS; i += DSP_THREADS) { S.frac[i] = T->bin_frac[i]; S.band[i] = T->bin_band[i]; }
+  if (tid < PN_NB + 2) S.border[tid] = T->border[tid];
+  if (tid < 8) S.comb_w[tid] = T->comb_hann[tid];
   __syncthreads();
 }
 
@@ -55,9 +79,8 @@ __device__ __forceinline__ void pn_stage_tables(PnDspShared &S, const PnTables *
 // Input must already be scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585).
 #define CMUL(m, a, b) do { (m).x = (a).x*(b).x - (a).y*(b).y; (m).y = (a).x*(b).y + (a).y*(b).x; } while (0)
 
-__device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw) {
-  const int lane = threadIdx.x;
-  __syncthreads();
+__device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw, int lane) {
+  PN_WAVE_SYNC();
   // radix-4, m=1 (degenerate twiddle-free butterfly, kiss_fft.cpp:112-131)
   for (int b = lane; b < 240; b += LANES) {
     float2 *f = F + 4 * b;
@@ -72,7 +95,7 @@ __device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw) {
     f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
     f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
   }
-  __syncthreads();
+  PN_WAVE_SYNC();
   // radix-4, m=4 (fstride 60, mm 16) then m=16 (fstride 15, mm 64)  (kiss_fft.cpp:139-166)
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
@@ -94,13 +117,14 @@ __device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw) {
       f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
       f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
   }
   // radix-3, m=64, fstride 5, mm 192 (kiss_fft.cpp:196-227); epi3 = tw[fstride*m]
   {
     const float epi3 = tw[320].y;
-    for (int b = lane; b < 320; b += LANES) {
-      const int i = b / 64, j = b % 64;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int j = lane;
       float2 *f = F + i * 192 + j;
       float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
       CMUL(s1, fm, tw[j * 5]); CMUL(s2, f2m, tw[2 * j * 5]);
@@ -113,12 +137,14 @@ __device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw) {
       fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
       f[0] = f0; f[64] = fm; f[128] = f2m;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
   }
   // radix-5, m=192, fstride 1 (kiss_fft.cpp:259-304); ya = tw[m], yb = tw[2m]
   {
     const float2 ya = tw[192], yb = tw[384];
-    for (int u = lane; u < 192; u += LANES) {
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const int u = lane + LANES * it;
       float2 *f = F + u;
       float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
       float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
@@ -143,22 +169,23 @@ __device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw) {
       f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
       f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
   }
 }
 
 // ---- band reductions (denoise.cpp:89-160): lane b owns band b, sums in the reference's order ---
-template <bool CORR>
-__device__ __forceinline__ float pn_band_reduce(const PnDspShared &S, const float2 *A, const float2 *Bc) {
-  const int b = threadIdx.x;
+// PROD = false: tmp = |A[k]|^2 formed on the fly (compute_band_energy);
+// PROD = true : tmp[k] precomputed per bin (compute_band_corr: X.r*P.r then += X.i*P.i).
+template <bool PROD>
+__device__ __forceinline__ float pn_band_reduce(const PnDspTablesLds &S, const float2 *A, const float *prod, int b) {
   float sum = 0;
   if (b < PN_NB) {
     if (b >= 1) {   // contributions `sum[i+1] += frac*tmp` of interval i = b-1
       const int lo = S.border[b - 1], hi = S.border[b];
       for (int k = lo; k < hi; k++) {
         float tmp;
-        if (CORR) { tmp = A[k].x * Bc[k].x; tmp += A[k].y * Bc[k].y; }
-        else      { tmp = A[k].x * A[k].x;  tmp += A[k].y * A[k].y; }
+        if (PROD) tmp = prod[k];
+        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
         sum += S.frac[k] * tmp;
       }
     }
@@ -166,8 +193,8 @@ __device__ __forceinline__ float pn_band_reduce(const PnDspShared &S, const floa
       const int lo = S.border[b], hi = S.border[b + 1];
       for (int k = lo; k < hi; k++) {
         float tmp;
-        if (CORR) { tmp = A[k].x * Bc[k].x; tmp += A[k].y * Bc[k].y; }
-        else      { tmp = A[k].x * A[k].x;  tmp += A[k].y * A[k].y; }
+        if (PROD) tmp = prod[k];
+        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
         sum += (1 - S.frac[k]) * tmp;
       }
     }
@@ -186,43 +213,83 @@ __device__ __forceinline__ int pn_ring(int j, int base_slot) {
 
 // window (apply_window, denoise.cpp:282-289) + 1/960 scale + digit-reverse scatter of 960 real
 // samples starting at logical history index j0
-__device__ __forceinline__ void pn_window_scatter(PnDspShared &S, const float *__restrict__ h, int base_slot, int j0) {
+__device__ __forceinline__ void pn_window_scatter(const PnDspTablesLds &S, float2 *F, const float *__restrict__ h,
+                                                  int base_slot, int j0, int lane) {
   const float scale = 1.f / PN_NFFT;
-  for (int i = threadIdx.x; i < PN_WINDOW; i += LANES) {
+#pragma unroll 5
+  for (int it = 0; it < 15; it++) {
+    const int i = lane + LANES * it;
     const float w = S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
     const float v = h[pn_ring(j0 + i, base_slot)] * w;
-    S.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+    F[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
   }
 }
 
+// acc + sum_{j<N} a[AS*j]*b[BS*j], adds strictly in j order (celt_inner_prod / xcorr_kernel /
+// dual_inner_prod, pitch.h:53-144).  Operands are fetched 16 ahead of the dependent add chain.
+template <int N, int AS, int BS>
+__device__ __forceinline__ float pn_chain(const float *a, const float *b, float acc) {
+  constexpr int U = 16;
+#pragma unroll 1
+  for (int j0 = 0; j0 + U <= N; j0 += U) {
+    float av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { av[u] = a[AS * (j0 + u)]; bv[u] = b[BS * (j0 + u)]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) acc = acc + av[u] * bv[u];
+  }
+  constexpr int R = N % U, J = N - R;
+  if (R) {
+    float av[R ? R : 1], bv[R ? R : 1];
+#pragma unroll
+    for (int u = 0; u < R; u++) { av[u] = a[AS * (J + u)]; bv[u] = b[BS * (J + u)]; }
+#pragma unroll
+    for (int u = 0; u < R; u++) acc = acc + av[u] * bv[u];
+  }
+  return acc;
+}
+
 // find_best_pitch (pitch.cpp:46-104, float instantiation); executed redundantly by every lane
-// (wave-uniform control flow, LDS broadcast reads).  y[j] = yb[ystride*j].
-__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *yb, int ystride, int len,
-                                                   int max_pitch, int &bp0, int &bp1) {
-  float Syy = 1, bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+// (wave-uniform control flow, LDS broadcast reads).  y[j] = yb[YS*j].
+template <int LEN, int MAXP, int YS>
+__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *yb, int &bp0, int &bp1) {
+  float Syy = pn_chain<LEN, YS, YS>(yb, yb, 1.0f);
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
   bp0 = 0; bp1 = 1;
-  for (int j = 0; j < len; j++) { const float v = yb[ystride * j]; Syy = Syy + v * v; }
-  for (int i = 0; i < max_pitch; i++) {
-    const float xc = xcorr[i];
-    if (xc > 0) {
-      float x16 = xc;
-      x16 *= 1e-12f;
-      const float num = x16 * x16;
-      if (num * bd1 > bn1 * Syy) {
-        if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = i; }
-        else { bn1 = num; bd1 = Syy; bp1 = i; }
+  constexpr int U = 8;
+#pragma unroll 1
+  for (int i0 = 0; i0 < MAXP; i0 += U) {
+    float xc[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = (i0 + u < MAXP) ? i0 + u : MAXP - 1;
+      xc[u] = xcorr[i];
+      const float a = yb[YS * (i + LEN)], c = yb[YS * i];
+      d[u] = a * a - c * c;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (i0 + u < MAXP) {
+        if (xc[u] > 0) {
+          float x16 = xc[u];
+          x16 *= 1e-12f;
+          const float num = x16 * x16;
+          if (num * bd1 > bn1 * Syy) {
+            if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = i0 + u; }
+            else { bn1 = num; bd1 = Syy; bp1 = i0 + u; }
+          }
+        }
+        Syy += d[u];
+        Syy = (1 > Syy) ? 1 : Syy;
       }
     }
-    const float a = yb[ystride * (i + len)], c = yb[ystride * i];
-    Syy += a * a - c * c;
-    Syy = (1 > Syy) ? 1 : Syy;
   }
 }
 
 __device__ __forceinline__ float pn_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
 
 template <typename TIn>
-__global__ __launch_bounds__(LANES) void pn_frontend_kernel(
+__global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_frontend_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t,
     const TIn *__restrict__ in,           // [n_streams][480]
     float *__restrict__ hist,             // [n_streams][12][480] ring
@@ -231,16 +298,19 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
     float *__restrict__ feat,             // [n_streams][PN_FEAT_STRIDE]
     int *__restrict__ silence,            // [n_streams]
     int *__restrict__ last_period, float *__restrict__ last_gain) {
-  __shared__ PnDspShared S;
-  const int lane = threadIdx.x;
-  pn_stage_tables(S, T);
+  __shared__ PnDspShared SH;
+  const int lane = threadIdx.x & (LANES - 1), wave = threadIdx.x >> 6;
+  pn_stage_tables(SH.t, T);
+  const PnDspTablesLds &S = SH.t;
+  PnDspWaveLds &W = SH.w[wave];
   const int new_slot = frame_t % PN_HIST_FRAMES;
   const int base_slot = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
-  float *pbuf = reinterpret_cast<float *>(S.fft);         // [864]  pitch scratch aliases the FFT buffer
+  float *pbuf = reinterpret_cast<float *>(W.fft);         // [864]  pitch scratch aliases the FFT buffer
   float *xcorr = pbuf + 864;                              // [294]
   float *yyl = xcorr + 296;                               // [385]
+  float *prod = reinterpret_cast<float *>(W.fft + 480);   // [400]  per-bin X.P products (entries >= 480 are free after the FFT)
 
-  for (int s = blockIdx.x; s < n_streams; s += gridDim.x) {
+  for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
     float *h = hist + (size_t)s * PN_HIST;
     // -- history: the shift+append of denoise.cpp:388-389 becomes one ring-slot write ---------
     for (int i = lane; i < PN_FRAME; i += LANES) {
@@ -249,39 +319,43 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
       else v = (float)in[(size_t)s * PN_FRAME + i];
       h[new_slot * PN_FRAME + i] = v;
     }
-    __syncthreads();
+    PN_WAVE_SYNC_GLOBAL();
     // -- X = FFT(window(comb_buf[2400,3360))), Ex (frame_analysis 333-346) ---------------------
-    pn_window_scatter(S, h, base_slot, 2400);
-    pn_fft960_lds(S.fft, S.tw);
-    for (int k = lane; k < PN_SPEC_BINS; k += LANES) { S.X[k] = S.fft[k]; Xspec[(size_t)s * PN_SPEC_BINS + k] = S.fft[k]; }
-    const float Ex = pn_band_reduce<false>(S, S.fft, nullptr);
-    __syncthreads();
+    pn_window_scatter(S, W.fft, h, base_slot, 2400, lane);
+    pn_fft960_lds(W.fft, S.tw, lane);
+    for (int k = lane; k < PN_SPEC_BINS; k += LANES) Xspec[(size_t)s * PN_SPEC_BINS + k] = W.fft[k];
+    const float Ex = pn_band_reduce<false>(S, W.fft, nullptr, lane);
+    PN_WAVE_SYNC();
     // -- look-ahead band energy of the newest 960 samples (498-506) ------------------------------
-    pn_window_scatter(S, h, base_slot, PN_HIST - PN_WINDOW);
-    pn_fft960_lds(S.fft, S.tw);
-    const float Ey = pn_band_reduce<false>(S, S.fft, nullptr);
-    __syncthreads();
+    pn_window_scatter(S, W.fft, h, base_slot, PN_HIST - PN_WINDOW, lane);
+    pn_fft960_lds(W.fft, S.tw, lane);
+    const float Ey = pn_band_reduce<false>(S, W.fft, nullptr, lane);
+    PN_WAVE_SYNC();
 
     // -- pitch_downsample (pitch.cpp:148-216) of pitch_buf == comb_buf[1632,3360) ----------------
-    for (int i = lane; i < 864; i += LANES) {
-      float v;
-      if (i == 0) v = .5f * (.5f * (h[pn_ring(1632 + 1, base_slot)]) + h[pn_ring(1632, base_slot)]);
-      else v = .5f * (.5f * (h[pn_ring(1632 + 2 * i - 1, base_slot)] + h[pn_ring(1632 + 2 * i + 1, base_slot)]) +
-                      h[pn_ring(1632 + 2 * i, base_slot)]);
-      pbuf[i] = v;
+#pragma unroll 2
+    for (int it = 0; it < 14; it++) {
+      const int i = lane + LANES * it;
+      if (i < 864) {
+        float v;
+        if (i == 0) v = .5f * (.5f * (h[pn_ring(1632 + 1, base_slot)]) + h[pn_ring(1632, base_slot)]);
+        else v = .5f * (.5f * (h[pn_ring(1632 + 2 * i - 1, base_slot)] + h[pn_ring(1632 + 2 * i + 1, base_slot)]) +
+                        h[pn_ring(1632 + 2 * i, base_slot)]);
+        pbuf[i] = v;
+      }
     }
-    __syncthreads();
-    // _celt_autocorr (celt_lpc.cpp:198-279): lane k holds lag k, sequential chains
-    float ack = 0;
-    if (lane <= 4) {
-      for (int j = 0; j < 860; j++) ack = ack + pbuf[j] * pbuf[j + lane];
-      float d = 0;
-      for (int i = lane + 860; i < 864; i++) d = d + pbuf[i] * pbuf[i - lane];
-      ack += d;
-    }
+    PN_WAVE_SYNC();
+    // _celt_autocorr (celt_lpc.cpp:198-279): lane k holds lag k (lanes > 4 shadow lag 4)
     float ac[5];
+    {
+      const int lag = lane < 4 ? lane : 4;
+      float ack = pn_chain<860, 1, 1>(pbuf, pbuf + lag, 0.f);
+      float d = 0;
+      for (int i = lag + 860; i < 864; i++) d = d + pbuf[i] * pbuf[i - lag];
+      ack += d;
 #pragma unroll
-    for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, k);
+      for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, k);
+    }
     ac[0] *= 1.0001f;
 #pragma unroll
     for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
@@ -340,36 +414,47 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
         }
         y[it] = sum;
       }
-      __syncthreads();
+      PN_WAVE_SYNC();
 #pragma unroll
       for (int it = 0; it < 14; it++) { const int i = lane + LANES * it; if (i < 864) pbuf[i] = y[it]; }
-      __syncthreads();
+      PN_WAVE_SYNC();
     }
 
     // -- pitch_search (pitch.cpp:283-386): x_lp = pbuf+384, y = pbuf, len 960, max_pitch 588 ----
-    // coarse: x_lp4[j] = pbuf[384+2j], y_lp4[j] = pbuf[2j]; one lane per lag, j-ascending chain
-    for (int i = lane; i < 147; i += LANES) {
-      float sum = 0;
-      for (int j = 0; j < 240; j++) sum = sum + pbuf[384 + 2 * j] * pbuf[2 * (i + j)];
-      xcorr[i] = sum;
+    // coarse: x_lp4[j] = pbuf[384+2j], y_lp4[j] = pbuf[2j]; lane owns lags {lane, lane+64, lane+128}
+    // (three independent j-ascending chains per lane)
+    {
+      const int i0 = lane, i1 = lane + 64, i2 = (lane + 128 < 147) ? lane + 128 : 146;
+      float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 1
+      for (int j0 = 0; j0 < 240; j0 += 8) {
+        float a[8], b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          a[u] = pbuf[384 + 2 * (j0 + u)];
+          b0[u] = pbuf[2 * (i0 + j0 + u)]; b1[u] = pbuf[2 * (i1 + j0 + u)]; b2[u] = pbuf[2 * (i2 + j0 + u)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s0 = s0 + a[u] * b0[u]; s1 = s1 + a[u] * b1[u]; s2 = s2 + a[u] * b2[u]; }
+      }
+      xcorr[i0] = s0; xcorr[i1] = s1;
+      if (lane + 128 < 147) xcorr[i2] = s2;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
     int bp0, bp1;
-    pn_find_best_pitch(xcorr, pbuf, 2, 240, 147, bp0, bp1);
-    __syncthreads();
+    pn_find_best_pitch<240, 147, 2>(xcorr, pbuf, bp0, bp1);
+    PN_WAVE_SYNC();
     // fine: only lags within +-2 of 2*best (pitch.cpp:344-361); other entries are 0
     for (int i = lane; i < 294; i += LANES) xcorr[i] = 0;
-    __syncthreads();
+    PN_WAVE_SYNC();
     {
       const int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
-      if (lane < 10 && c >= 0 && c < 294) {
-        float sum = 0;
-        for (int j = 0; j < 480; j++) sum = sum + pbuf[384 + j] * pbuf[c + j];
-        xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
-      }
+      const bool act = lane < 10 && c >= 0 && c < 294;
+      const float sum = pn_chain<480, 1, 1>(pbuf + 384, pbuf + (act ? c : 0), 0.f);
+      if (act) xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
     }
-    __syncthreads();
-    pn_find_best_pitch(xcorr, pbuf, 1, 480, 294, bp0, bp1);
+    PN_WAVE_SYNC();
+    pn_find_best_pitch<480, 294, 1>(xcorr, pbuf, bp0, bp1);
     int offset = 0;
     if (bp0 > 0 && bp0 < 294 - 1) {
       const float a = xcorr[bp0 - 1], b = xcorr[bp0], c = xcorr[bp0 + 1];
@@ -378,7 +463,7 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
     }
     const float pitch_corr = xcorr[bp0];
     int pitch_index = PN_PITCH_MAX - (2 * bp0 - offset);       // denoise.cpp:408
-    __syncthreads();
+    PN_WAVE_SYNC();
 
     // -- remove_doubling (pitch.cpp:424-527): maxperiod 384, minperiod 30, N 480, x = pbuf+384 -----
     float pg;
@@ -390,32 +475,38 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
       if (T0 >= 384) T0 = 383;
       // lane 0: xx, lane 1: xy(T0), lanes 2..15: xy(T1_k), lanes 16..29: xy2(T1b_k)  (k = 2..15)
       int lag = 0, T1 = 0, T1b = 0;
-      bool active = false;
       const int k = (lane >= 16) ? lane - 14 : lane;            // lanes 2..15 and 16..29 -> k = 2..15
-      if (lane == 0) { lag = 0; active = true; }
-      else if (lane == 1) { lag = T0; active = true; }
-      else if (lane < 30) {
+      if (lane == 1) lag = T0;
+      else if (lane >= 2 && lane < 30) {
         static const int second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
         T1 = (2 * T0 + k) / (2 * k);
         if (k == 2) { if (T1 + T0 > 384) T1b = T0; else T1b = T0 + T1; }
         else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
         lag = (lane < 16) ? T1 : T1b;
-        active = true;
       }
-      float dot = 0;
-      if (active) for (int i = 0; i < 480; i++) dot = dot + x[i] * x[i - lag];
+      const float dot = pn_chain<480, 1, 1>(x, x - lag, 0.f);   // lanes >= 30 shadow lag 0
       const float xx = __shfl(dot, 0);
       float xy = __shfl(dot, 1);
       // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, wave-uniform
       {
         float yy = xx;
         if (lane == 0) yyl[0] = xx;
-        for (int i = 1; i <= 384; i++) {
-          yy = yy + x[-i] * x[-i] - x[480 - i] * x[480 - i];
-          if (lane == 0) yyl[i] = (0 > yy) ? 0 : yy;
+#pragma unroll 1
+        for (int i0 = 1; i0 <= 384; i0 += 16) {
+          float p[16], q[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            const float a = x[-(i0 + u)], c = x[480 - (i0 + u)];
+            p[u] = a * a; q[u] = c * c;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            yy = yy + p[u] - q[u];
+            if (lane == 0) yyl[i0 + u] = (0 > yy) ? 0 : yy;
+          }
         }
       }
-      __syncthreads();
+      PN_WAVE_SYNC();
       float yy = yyl[T0];
       float best_xy = xy, best_yy = yy;
       const float g0 = pn_pitch_gain(xy, xx, yy);
@@ -423,7 +514,7 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
       int Tsel = T0;
       // k = 2..15 evaluated in parallel on lanes 2..15; the sequential loop's "last hit wins"
       // becomes "highest k among hits"; its `break` at T1 < minperiod is a prefix condition.
-      const float xy2 = __shfl(dot, lane + 14);     // partner lane holds xy2 for the same k
+      const float xy2 = __shfl(dot, (lane + 14) & 63);          // partner lane holds xy2 for the same k
       bool hit = false;
       float xyk = 0, yyk = 0, g1 = 0;
       if (lane >= 2 && lane < 16 && T1 >= 30) {
@@ -447,8 +538,7 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
       }
       best_xy = (0 > best_xy) ? 0 : best_xy;
       if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
-      float xc = 0;
-      if (lane < 3) for (int i = 0; i < 480; i++) xc = xc + x[i] * x[i - (Tsel + lane - 1)];
+      const float xc = pn_chain<480, 1, 1>(x, x - (Tsel + (lane < 3 ? lane : 2) - 1), 0.f);
       const float xc0 = __shfl(xc, 0), xc1 = __shfl(xc, 1), xc2 = __shfl(xc, 2);
       int off2;
       if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
@@ -459,41 +549,52 @@ __global__ __launch_bounds__(LANES) void pn_frontend_kernel(
       if (pitch_index < PN_PITCH_MIN) pitch_index = PN_PITCH_MIN;
     }
     if (lane == 0) { last_period[s] = pitch_index; last_gain[s] = pg; }
-    __syncthreads();
+    PN_WAVE_SYNC();
 
     // -- comb filter (denoise.cpp:416-422) + window + FFT -> P, Ep, Exp -------------------------
     {
       const float scale = 1.f / PN_NFFT;
-      for (int i = lane; i < PN_WINDOW; i += LANES) {
+#pragma unroll 3
+      for (int it = 0; it < 15; it++) {
+        const int i = lane + LANES * it;
         float p = 0;
 #pragma unroll
         for (int k = -PN_COMB_M; k <= PN_COMB_M; k++)
           p += h[pn_ring(2400 - pitch_index * k + i, base_slot)] * S.comb_w[k + PN_COMB_M];
         const float v = p * S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
-        S.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+        W.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
       }
     }
-    pn_fft960_lds(S.fft, S.tw);
-    for (int k = lane; k < PN_SPEC_BINS; k += LANES) Pspec[(size_t)s * PN_SPEC_BINS + k] = S.fft[k];
-    const float Ep = pn_band_reduce<false>(S, S.fft, nullptr);
-    float Exp = pn_band_reduce<true>(S, S.X, S.fft);
+    pn_fft960_lds(W.fft, S.tw, lane);
+    PN_WAVE_SYNC_GLOBAL();                   // X was stored by this wave earlier in the iteration
+    for (int k = lane; k < PN_SPEC_BINS; k += LANES) {
+      const float2 P = W.fft[k];
+      const float2 X = Xspec[(size_t)s * PN_SPEC_BINS + k];
+      Pspec[(size_t)s * PN_SPEC_BINS + k] = P;
+      float tmp = X.x * P.x;                 // compute_band_corr's per-bin term (denoise.cpp:136-137)
+      tmp += X.y * P.y;
+      prod[k] = tmp;
+    }
+    const float Ep = pn_band_reduce<false>(S, W.fft, nullptr, lane);
+    PN_WAVE_SYNC();
+    float Exp = pn_band_reduce<true>(S, nullptr, prod, lane);
     if (lane < PN_NB) {
       // double island, denoise.cpp:427
       Exp = (float)fmin(1.0, fmax(0.0, (double)Exp / sqrt(1e-15 + (double)(Ex * Ep))));
-      S.e[0][lane] = Ex;
+      W.e[0][lane] = Ex;
     }
-    __syncthreads();
-    // silence = sum(Ex) < 0.1 (429-433): sequential sum, wave-uniform
+    PN_WAVE_SYNC();
+    // silence = sum(Ex) < 0.1 (429-433): sequential sum
     if (lane == 0) {
       float E = 0;
-      for (int i = 0; i < PN_NB; i++) E += S.e[0][i];
+      for (int i = 0; i < PN_NB; i++) E += W.e[0][i];
       silence[s] = ((double)E < 0.1) ? 1 : 0;
     }
     // -- create_features (487-496) -----------------------------------------------------------------
     float *f = feat + (size_t)s * PN_FEAT_STRIDE;
     if (lane < PN_NB) { f[lane] = Ey * 30; f[PN_NB + lane] = Exp * 30; }
     if (lane == 0) { f[68] = (float)pitch_index / (PN_PITCH_MAX - 3 * PN_PITCH_MIN); f[69] = pitch_corr; }
-    __syncthreads();
+    PN_WAVE_SYNC();
   }
 }
 
@@ -505,28 +606,32 @@ __device__ __forceinline__ int16_t pn_f2s(float v) {
 }
 
 template <typename TOut>
-__global__ __launch_bounds__(LANES) void pn_backend_kernel(
+__global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend_kernel(
     const PnTables *__restrict__ T, int n_streams,
     const float2 *__restrict__ Xspec, const float2 *__restrict__ Pspec,
     const float *__restrict__ gr,          // [n_streams][68]  g | r
     const int *__restrict__ silence,
     float *__restrict__ synth_mem,         // [n_streams][480]
     TOut *__restrict__ out) {              // [n_streams][480]
-  __shared__ PnDspShared S;
-  const int lane = threadIdx.x;
-  pn_stage_tables(S, T);
+  __shared__ PnDspShared SH;
+  const int lane = threadIdx.x & (LANES - 1), wave = threadIdx.x >> 6;
+  pn_stage_tables(SH.t, T);
+  const PnDspTablesLds &S = SH.t;
+  PnDspWaveLds &W = SH.w[wave];
   const float scale = 1.f / PN_NFFT;
-  for (int s = blockIdx.x; s < n_streams; s += gridDim.x) {
+  for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
     if (lane < PN_NB) {
       const float g = gr[(size_t)s * 68 + lane], r = gr[(size_t)s * 68 + PN_NB + lane];
-      S.e[0][lane] = g; S.e[1][lane] = r; S.e[2][lane] = 1 - r;
+      W.e[0][lane] = g; W.e[1][lane] = r; W.e[2][lane] = 1 - r;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
     const bool sil = silence[s] != 0;
     // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian
     // extension + scale + digit-reverse scatter of inverse_transform (306-317).  Bins >= 400
     // are exactly 0 (interp_band_gain never writes them).
-    for (int i = lane; i < PN_WINDOW; i += LANES) {
+#pragma unroll 3
+    for (int it = 0; it < 15; it++) {
+      const int i = lane + LANES * it;
       const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
       float2 x = make_float2(0.f, 0.f);
       if (k < PN_SPEC_BINS) {
@@ -535,37 +640,38 @@ __global__ __launch_bounds__(LANES) void pn_backend_kernel(
         const float fr = S.frac[k];
         if (!sil) {
           const float2 p = Pspec[(size_t)s * PN_SPEC_BINS + k];
-          const float rf1 = (1 - fr) * S.e[2][b] + fr * S.e[2][b + 1];
+          const float rf1 = (1 - fr) * W.e[2][b] + fr * W.e[2][b + 1];
           x.x = rf1 * x.x; x.y = rf1 * x.y;
-          const float rf2 = (1 - fr) * S.e[1][b] + fr * S.e[1][b + 1];
+          const float rf2 = (1 - fr) * W.e[1][b] + fr * W.e[1][b + 1];
           x.x += rf2 * p.x; x.y += rf2 * p.y;
         }
-        const float gf = (1 - fr) * S.e[0][b] + fr * S.e[0][b + 1];
+        const float gf = (1 - fr) * W.e[0][b] + fr * W.e[0][b + 1];
         x.x *= gf; x.y *= gf;
       }
       if (i > PN_FRAME) x.y = -x.y;
-      S.fft[S.bitrev[i]] = make_float2(scale * x.x, scale * x.y);
+      W.fft[S.bitrev[i]] = make_float2(scale * x.x, scale * x.y);
     }
-    pn_fft960_lds(S.fft, S.tw);
+    pn_fft960_lds(W.fft, S.tw, lane);
     // reversed read-out x960 (318-323), window, overlap-add (352-359)
     float *sm = synth_mem + (size_t)s * PN_FRAME;
     for (int i = lane; i < PN_FRAME; i += LANES) {
-      const float t_lo = (PN_WINDOW * S.fft[i == 0 ? 0 : PN_WINDOW - i].x) * S.win[i];
+      const float t_lo = (PN_WINDOW * W.fft[i == 0 ? 0 : PN_WINDOW - i].x) * S.win[i];
       const int i2 = PN_FRAME + i;                       // second half, window index 959 - i2
-      const float t_hi = (PN_WINDOW * S.fft[PN_WINDOW - i2].x) * S.win[PN_WINDOW - 1 - i2];
+      const float t_hi = (PN_WINDOW * W.fft[PN_WINDOW - i2].x) * S.win[PN_WINDOW - 1 - i2];
       const float o = t_lo + sm[i];
       sm[i] = t_hi;
       if (sizeof(TOut) == 2) out[(size_t)s * PN_FRAME + i] = (TOut)pn_f2s(o * 32768);
       else out[(size_t)s * PN_FRAME + i] = (TOut)o;
     }
-    __syncthreads();
+    PN_WAVE_SYNC();
   }
 }
 
 // ---- launchers -------------------------------------------------------------------------------
 static inline int pn_dsp_grid(int n_streams) {
-  const int cap = 256 * 6;   // 256 CUs x 6 resident single-wave blocks (LDS-limited)
-  return n_streams < cap ? n_streams : cap;
+  const int need = (n_streams + WPB - 1) / WPB;
+  const int cap = 256 * (PN_DSP_WAVES_PER_SIMD * 4 / WPB);   // 256 CUs x resident blocks per CU
+  return need < cap ? need : cap;
 }
 
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int frame_t, const void *in, int in_is_i16,
@@ -573,10 +679,10 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int fr
                         float *last_gain) {
   const int grid = pn_dsp_grid(n_streams);
   if (in_is_i16)
-    hipLaunchKernelGGL(pn_frontend_kernel<int16_t>, dim3(grid), dim3(LANES), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_frontend_kernel<int16_t>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, frame_t,
                        (const int16_t *)in, hist, Xs, Ps, feat, silence, last_period, last_gain);
   else
-    hipLaunchKernelGGL(pn_frontend_kernel<float>, dim3(grid), dim3(LANES), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_frontend_kernel<float>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, frame_t,
                        (const float *)in, hist, Xs, Ps, feat, silence, last_period, last_gain);
 }
 
@@ -584,9 +690,9 @@ void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const f
                        const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16) {
   const int grid = pn_dsp_grid(n_streams);
   if (out_is_i16)
-    hipLaunchKernelGGL(pn_backend_kernel<int16_t>, dim3(grid), dim3(LANES), 0, st, T, n_streams, Xs, Ps, gr, silence,
+    hipLaunchKernelGGL(pn_backend_kernel<int16_t>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, Xs, Ps, gr, silence,
                        synth_mem, (int16_t *)out);
   else
-    hipLaunchKernelGGL(pn_backend_kernel<float>, dim3(grid), dim3(LANES), 0, st, T, n_streams, Xs, Ps, gr, silence,
+    hipLaunchKernelGGL(pn_backend_kernel<float>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, Xs, Ps, gr, silence,
                        synth_mem, (float *)out);
 }

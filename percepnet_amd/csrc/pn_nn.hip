@@ -42,7 +42,11 @@ enum { ACT_LINEAR = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_RELU = 3 };
 __device__ __forceinline__ float pn_tansig(float x, const float *tab) {
   float sign = 1;
   if (x < 0) { x = -x; sign = -1; }
-  int i = (int)floorf(.5f + 25 * x);
+  const float v = floorf(.5f + 25 * x);
+  // the reference's x86-64 build converts with cvttss2si: out-of-range / NaN -> INT_MIN, which
+  // the clamp below then turns into index 0 (not 200); mirrored here so that even absurd
+  // pre-activations (> 8.6e7) behave like the CPU path
+  int i = (v < 2147483648.f) ? (int)v : (int)0x80000000;
   i = i > 200 ? 200 : i;
   i = i < 0 ? 0 : i;
   x -= .04f * i;

@@ -15,7 +15,7 @@ Produces
   pcm_golden.npz          int16 PCM in / PCM out / g,r tap of the compiled reference
                           (percepNet_run semantics) for streams 0 (voiced), 3 (loud: non-silent
                           frames), 7 (bursts+silence), 13 (two-tone), 48 frames each, plus
-                          float-in/float-out of stream 0 and of stream 3 at int16 scale.
+                          float-in/float-out of stream 0 and of stream 3 at 4x scale.
 """
 import ctypes
 import hashlib
@@ -100,9 +100,11 @@ def main():
     x = synth.synth_stream(0, 48).astype(np.float32) / np.float32(32768)
     fo, fgr = ref.run_float(x)
     g["fin_0"] = x; g["fout_0"] = fo
-    # original-RNNoise sample convention (floats at int16 scale, no /32768): every frame is
-    # "non-silent", exercising the pitch-filter branch at a very different numeric range
-    x3 = synth.synth_stream(3, 48).astype(np.float32)
+    # float API with samples beyond the nominal [-1,1) (x4): nearly every frame is "non-silent",
+    # exercising the pitch-filter branch at a different numeric range.  (Feeding int16-SCALE
+    # floats, the original RNNoise convention, overflows the float->int conversion inside
+    # tansig_approx, vec.h:61, which is undefined behaviour in the reference — not a test case.)
+    x3 = synth.synth_stream(3, 48).astype(np.float32) / np.float32(32768) * np.float32(4)
     fo3, fgr3 = ref.run_float(x3)
     g["fin_3"] = x3; g["fout_3"] = fo3; g["fgr_3"] = fgr3
     np.savez_compressed(os.path.join(HERE, "pcm_golden.npz"), **g)
