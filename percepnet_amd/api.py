@@ -27,6 +27,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if torch is going
+    # to be used in this process (tests, bench) it must be loaded BEFORE this library so that
+    # both bind to the same runtime copy (loading order reversed, torch reports "No HIP GPUs").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = os.environ.get("PERCEPNET_LIB", LIB_PATH)   # override: tuning variants (build.build_variant)
     if not os.path.exists(path):
         raise PercepNetError(

@@ -430,3 +430,27 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
   c->t++;
   return 0;
 }
+
+// Debug tap (tests/tools only): copy an internal device buffer to the host.
+// which: 0 feat[B][96], 1 c1ring[5][B][128], 2 c2ring[3][B][512], 3 c2out[B][512],
+//        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68].  Returns the byte count.
+extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long long max_bytes) {
+  if (!c || !dst) return -1;
+  const size_t B = c->B;
+  const void *src = NULL; size_t n = 0;
+  switch (which) {
+    case 0: src = c->feat; n = B * PN_FEAT_STRIDE * 4; break;
+    case 1: src = c->c1ring; n = 5 * B * 128 * 4; break;
+    case 2: src = c->c2ring; n = 3 * B * 512 * 4; break;
+    case 3: src = c->c2out; n = B * 512 * 4; break;
+    case 4: case 5: case 6: case 7: src = c->gru[which - 4]; n = 2 * B * 512 * 4; break;
+    case 8: src = c->rb; n = 2 * B * 128 * 4; break;
+    case 9: src = c->gr; n = B * 68 * 4; break;
+    default: pn_set_error("bad debug buffer id"); return -1;
+  }
+  if ((long long)n > max_bytes) { pn_set_error("debug buffer needs %zu bytes", n); return -1; }
+  if (hipSetDevice(c->device) != hipSuccess) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) { pn_set_error("debug copy failed"); return -1; }
+  return (long long)n;
+}

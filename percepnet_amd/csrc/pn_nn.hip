@@ -32,7 +32,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct PnSegs {           // A operand = concatenation along K of up to 5 row-major panels
   const float *p[5];
   int ld[5];              // row stride (floats)
-  int width[5];           // valid columns (zero-filled up to the next multiple of 32)
+  int width[5];           // valid columns; the MFMA path requires every panel to be readable (and
+                          // zero) up to the next multiple of 32 and all panels to be equally wide
   int n;
 };
 
@@ -126,26 +127,17 @@ struct NnShared {
   float tansig[208];
 };
 
-// stage a 128 x 32 activation tile: rows m0.., columns k0..k0+31 of panel p (zero beyond `width`
-// and beyond n_rows), k-interleaved into S.A
-__device__ __forceinline__ void pn_stage_A(float (*As)[LDT], const float *__restrict__ p, int ld, int width, int k0,
+// stage a 128 x 32 activation tile: rows m0.., columns k0..k0+31 of panel p (zero beyond
+// n_rows), k-interleaved into S.A.  Panels are padded to a multiple of 32 columns.
+__device__ __forceinline__ void pn_stage_A(float (*As)[LDT], const float *__restrict__ p, int ld, int k0,
                                            int m0, int n_rows) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int idx = tid + NN_THREADS * it;
     const int row = idx >> 3, c = idx & 7;        // 8 float4 per row
-    const int k = k0 + 4 * c;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + row < n_rows) {
-      const float *src = p + (size_t)(m0 + row) * ld + k;
-      if (k + 3 < width) v = *reinterpret_cast<const float4 *>(src);
-      else {
-        if (k < width) v.x = src[0];
-        if (k + 1 < width) v.y = src[1];
-        if (k + 2 < width) v.z = src[2];
-      }
-    }
+    if (m0 + row < n_rows) v = *reinterpret_cast<const float4 *>(p + (size_t)(m0 + row) * ld + k0 + 4 * c);
     // k_local = 4c + {0,1,2,3}: q = c>>1, (kh,s) = (0,2(c&1)), (1,2(c&1)), (0,2(c&1)+1), (1,2(c&1)+1)
     float *dst = &As[row][(c >> 1) * 8 + 2 * (c & 1)];
     *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
@@ -161,8 +153,21 @@ __device__ __forceinline__ void pn_stage_B(float (*Bs)[LDT], const float *__rest
   *reinterpret_cast<float4 *>(&Bs[j][4 * c]) = v;
 }
 
+// Toolchain hazard found on ROCm 7.2 / gfx950 (DESIGN.md "MFMA result hazard"): when a loop of
+// v_mfma_f32_32x32x2_f32 exits, hipcc places the first read of the accumulator tuple (a
+// v_accvgpr_mov of element 15, the register the 16th pass writes last) only `s_nop 1` after the
+// final MFMA, and that read returns the value from BEFORE it: output rows 27/31 (mod 32) silently
+// lose the last k-step.  The hazard recogniser does not look across the loop back-edge / exit
+// copies.  Every K-tile therefore ends with an explicit drain of the matrix pipe (32 wait states
+// >= the 19 a 16-pass MFMA needs), pinned in place with scheduling barriers: ~1 % of a K-tile.
+__device__ __forceinline__ void pn_mfma_drain() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int NT>
-__device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 (&acc)[NT],
+__device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
                                              int wave, int lane) {
   const int r = lane & 31, kh = lane >> 5;
 #pragma unroll
@@ -180,6 +185,7 @@ __device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
   }
+  pn_mfma_drain();
 }
 
 // XCD-aware block numbering: hardware places block b on XCD b % 8; give each XCD whole
@@ -192,10 +198,10 @@ __device__ __forceinline__ bool pn_tile_of_block(int n_mtiles, int n_ctiles, int
 }
 
 // Dense / conv-as-dense: out[m][n] = act(bias[n] + sum_k A[m][k] W[k][n]); Wp packed
-// [ctile][ktile][32 cols][32 k-interleaved]; NT column tiles per block.
+// [ctile][ktile][32 cols][32 k-interleaved]; NT column tiles per block.  tps = K-tiles per panel.
 template <int NT>
 __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
-    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int act,
+    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
     const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
   __shared__ NnShared S;
   int mt, cb;
@@ -211,17 +217,15 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[t][i] = bv;
   }
-  int kt = 0;
-  for (int sg = 0; sg < A.n; sg++) {
-    for (int k0 = 0; k0 < A.width[sg]; k0 += BK, kt++) {
-      __syncthreads();
-      pn_stage_A(S.A, A.p[sg], A.ld[sg], A.width[sg], k0, m0, n_rows);
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt++) {
+    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
+    __syncthreads();
+    pn_stage_A(S.A, A.p[sg], A.ld[sg], k0, m0, n_rows);
 #pragma unroll
-      for (int t = 0; t < NT; t++)
-        pn_stage_B(&S.B[32 * t], Wp + ((size_t)(cb * NT + t) * KT + kt) * 1024);
-      __syncthreads();
-      pn_mma_ktile<NT>(S.A, S.B, acc, wave, lane);
-    }
+    for (int t = 0; t < NT; t++) pn_stage_B(&S.B[32 * t], Wp + ((size_t)(cb * NT + t) * KT + kt) * 1024);
+    __syncthreads();
+    pn_mma_ktile<NT>(S.A, S.B, acc, wave, lane);
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -236,9 +240,10 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
 
 // Reset-after GRU step for a 128-stream x 32-neuron tile.
 // Wp: packed input weights  [3N/32 ctiles][KTx][32][32]; Up: packed recurrent [3N/32][N/32][32][32].
+// acc[0..3] = z, r, tmp (= b_rh + U_h h), h.
 __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int act, const float *__restrict__ tansig,
+    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
     float *__restrict__ h_new, int n_rows, int n_mtiles) {
   __shared__ NnShared S;
   const int NTn = N >> 5;                       // neuron tiles
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
   const int col = nt * 32 + (lane & 31);
   if (tid < 201) S.tansig[tid] = tansig[tid];
 
-  floatx16 acc[3];                              // z, r, tmp
+  floatx16 acc[4];
   {
     float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
     float br = b[N + col]; br += b[4 * N + col];// 147-153
@@ -258,31 +263,27 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = bt; }
   }
   // z,r += W_{z,r} x
-  {
-    floatx16 zr[2] = {acc[0], acc[1]};
-    int kt = 0;
-    for (int sg = 0; sg < X.n; sg++)
-      for (int k0 = 0; k0 < X.width[sg]; k0 += BK, kt++) {
-        __syncthreads();
-        pn_stage_A(S.A, X.p[sg], X.ld[sg], X.width[sg], k0, m0, n_rows);
-        pn_stage_B(&S.B[0], Wp + ((size_t)(0 * NTn + nt) * KTx + kt) * 1024);
-        pn_stage_B(&S.B[32], Wp + ((size_t)(1 * NTn + nt) * KTx + kt) * 1024);
-        __syncthreads();
-        pn_mma_ktile<2>(S.A, S.B, zr, wave, lane);
-      }
-    acc[0] = zr[0]; acc[1] = zr[1];
+#pragma unroll 1
+  for (int kt = 0; kt < KTx; kt++) {
+    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
+    __syncthreads();
+    pn_stage_A(S.A, X.p[sg], X.ld[sg], k0, m0, n_rows);
+    pn_stage_B(&S.B[0], Wp + ((size_t)(0 * NTn + nt) * KTx + kt) * 1024);
+    pn_stage_B(&S.B[32], Wp + ((size_t)(1 * NTn + nt) * KTx + kt) * 1024);
+    __syncthreads();
+    pn_mma_ktile<2>(S.A, S.B, acc, wave, lane);
   }
   // z,r,tmp += U_{z,r,h} h_old
+#pragma unroll 1
   for (int kt = 0; kt < KTh; kt++) {
     __syncthreads();
-    pn_stage_A(S.A, h_old, N, N, kt * BK, m0, n_rows);
+    pn_stage_A(S.A, h_old, N, kt * BK, m0, n_rows);
 #pragma unroll
     for (int g = 0; g < 3; g++) pn_stage_B(&S.B[32 * g], Up + ((size_t)(g * NTn + nt) * KTh + kt) * 1024);
     __syncthreads();
     pn_mma_ktile<3>(S.A, S.B, acc, wave, lane);
   }
   // gates; h = b_h + tmp * r  (nnet.cpp:144,156,161-166)
-  floatx16 hh[1];
   {
     const float bh = b[2 * N + col];
 #pragma unroll
@@ -291,27 +292,25 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
       acc[1][i] = pn_sigmoid(acc[1][i], S.tansig);
       float h = bh;
       h += acc[2][i] * acc[1][i];
-      hh[0][i] = h;
+      acc[3][i] = h;
     }
   }
   // h += W_h x  (nnet.cpp:167)
-  {
-    int kt = 0;
-    for (int sg = 0; sg < X.n; sg++)
-      for (int k0 = 0; k0 < X.width[sg]; k0 += BK, kt++) {
-        __syncthreads();
-        pn_stage_A(S.A, X.p[sg], X.ld[sg], X.width[sg], k0, m0, n_rows);
-        pn_stage_B(&S.B[0], Wp + ((size_t)(2 * NTn + nt) * KTx + kt) * 1024);
-        __syncthreads();
-        pn_mma_ktile<1>(S.A, S.B, hh, wave, lane);
-      }
+#pragma unroll 1
+  for (int kt = 0; kt < KTx; kt++) {
+    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
+    __syncthreads();
+    pn_stage_A(S.A, X.p[sg], X.ld[sg], k0, m0, n_rows);
+    pn_stage_B(&S.B[0], Wp + ((size_t)(2 * NTn + nt) * KTx + kt) * 1024);
+    __syncthreads();
+    pn_mma_ktile<1>(S.A, S.B, acc + 3, wave, lane);
   }
   // activation + blend (nnet.cpp:175-179)
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     if (row < n_rows) {
-      const float hv = pn_act(hh[0][i], act, S.tansig);
+      const float hv = pn_act(acc[3][i], act, S.tansig);
       const float z = acc[0][i];
       const float ho = h_old[(size_t)row * N + col];
       h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
@@ -353,18 +352,17 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
     hipLaunchKernelGGL(pn_dense_strict_kernel, grid, dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo);
     return;
   }
-  int KT = 0;
-  for (int sg = 0; sg < A.n; sg++) KT += (A.width[sg] + 31) / 32;
+  const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
   const int NT = pn_dense_nt(N);
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
   if (NT == 4)
-    hipLaunchKernelGGL(pn_dense_mfma_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, act, tansig,
-                       out, ldo, n_rows, n_mtiles, n_cblocks);
+    hipLaunchKernelGGL(pn_dense_mfma_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   else
-    hipLaunchKernelGGL(pn_dense_mfma_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, act, tansig,
-                       out, ldo, n_rows, n_mtiles, n_cblocks);
+    hipLaunchKernelGGL(pn_dense_mfma_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
 }
 
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
@@ -375,10 +373,9 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
     hipLaunchKernelGGL(pn_gru_strict_kernel, grid, dim3(64), 0, st, X, h_old, W, U, b, N, act, tansig, h_new);
     return;
   }
-  int KTx = 0;
-  for (int sg = 0; sg < X.n; sg++) KTx += (X.width[sg] + 31) / 32;
+  const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-  hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, act, tansig,
-                     h_new, n_rows, n_mtiles);
+  hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+                     tansig, h_new, n_rows, n_mtiles);
 }
