@@ -163,16 +163,13 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from percepnet_amd.sharding import aggregate_throughput
+    fps, dt = aggregate_throughput(dist if world > 1 else None, B * K, dt)   # SUM frames / MAX time
 
     kt = {} if a.no_profile else ctx.kernel_times()
     checksum = int(out.to(torch.int64).abs().sum().item())     # keeps the result live / sanity
 
     if rank == 0:
-        fps = n_gpus * B * K / dt
         res = {
             "metric": "real-time 48 kHz streams (10 ms frames), whole job",
             "value": round(fps / 100.0, 1),
