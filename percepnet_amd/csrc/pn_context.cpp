@@ -139,6 +139,7 @@ struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
 
 struct pn_ctx {
   int device, B, nn_mode;
+  size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
   int64_t t;                       // frames done
   size_t bytes;
@@ -178,12 +179,13 @@ static int zero_state(pn_ctx *c) {
   PN_HIP_CHECK(hipMemsetAsync(c->last_gain, 0, B * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->last_period, 0, B * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->silence, 0, B * 4, c->stream));
-  PN_HIP_CHECK(hipMemsetAsync(c->feat, 0, B * PN_FEAT_STRIDE * 4, c->stream));
-  PN_HIP_CHECK(hipMemsetAsync(c->c1ring, 0, 5 * B * 128 * 4, c->stream));
-  PN_HIP_CHECK(hipMemsetAsync(c->c2ring, 0, 3 * B * 512 * 4, c->stream));
-  PN_HIP_CHECK(hipMemsetAsync(c->c2out, 0, B * 512 * 4, c->stream));
-  for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gru[i], 0, 2 * B * 512 * 4, c->stream));
-  PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * B * 128 * 4, c->stream));
+  const size_t Bp = c->Bp;
+  PN_HIP_CHECK(hipMemsetAsync(c->feat, 0, Bp * PN_FEAT_STRIDE * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c1ring, 0, 5 * Bp * 128 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c2ring, 0, 3 * Bp * 512 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->c2out, 0, Bp * 512 * 4, c->stream));
+  for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gru[i], 0, 2 * Bp * 512 * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * Bp * 128 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->gr, 0, B * 68 * 4, c->stream));
   c->t = 0;
   return 0;
@@ -211,7 +213,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   if (device < 0 || device >= ndev) { pn_set_error("device %d out of range (%d devices)", device, ndev); return NULL; }
   if (hipSetDevice(device) != hipSuccess) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -219,7 +221,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { pn_set_error("hipStreamCreate failed"); delete c; return NULL; }
     c->own_stream = true;
   }
-  const size_t B = n_streams;
+  const size_t B = n_streams, Bp = c->Bp;
   {
     PnTables *ht = new PnTables();
     pn_build_tables(ht);
@@ -237,12 +239,12 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   DEV_ALLOC(c->silence, B, false);
   DEV_ALLOC(c->Xs, B * PN_SPEC_BINS, true);
   DEV_ALLOC(c->Ps, B * PN_SPEC_BINS, true);
-  DEV_ALLOC(c->feat, B * PN_FEAT_STRIDE, false);
-  DEV_ALLOC(c->c1ring, 5 * B * 128, false);
-  DEV_ALLOC(c->c2ring, 3 * B * 512, false);
-  DEV_ALLOC(c->c2out, B * 512, false);
-  for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * B * 512, false);
-  DEV_ALLOC(c->rb, 2 * B * 128, false);
+  DEV_ALLOC(c->feat, Bp * PN_FEAT_STRIDE, false);
+  DEV_ALLOC(c->c1ring, 5 * Bp * 128, false);
+  DEV_ALLOC(c->c2ring, 3 * Bp * 512, false);
+  DEV_ALLOC(c->c2out, Bp * 512, false);
+  for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * Bp * 512, false);
+  DEV_ALLOC(c->rb, 2 * Bp * 128, false);
   DEV_ALLOC(c->gr, B * 68, false);
   DEV_ALLOC(c->io_in, B * PN_FRAME, false);
   DEV_ALLOC(c->io_out, B * PN_FRAME, false);
@@ -327,34 +329,34 @@ static PnSegs seg1(const float *p, int ld, int width) { PnSegs s; memset(&s, 0, 
 
 // compute_rnn (rnn.cpp:42-81) for all streams; features in c->feat, result in c->gr
 static void launch_rnn(pn_ctx *c) {
-  const size_t B = c->B; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
+  const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
   hipStream_t st = c->stream; const float *tab = c->tansig;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
-  float *c1new = c->c1ring + (size_t)(t % 5) * B * 128;
-  float *c2new = c->c2ring + (size_t)(t % 3) * B * 512;
+  float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128;
+  float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512;
   { Scope sc(c, KF_FC);
-    PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, PN_NFEAT);
+    PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..95 are zero
     pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B); }
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
-    for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * B * 128; A.ld[j] = 128; A.width[j] = 128; }
+    for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
     pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
-    for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * B * 512; A.ld[j] = 512; A.width[j] = 512; }
+    for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
     pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B); }
   const float *x = c->c2out;
   for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
     Scope sc(c, KF_GRU512);
     const int li = PN_L_GRU1 + i;
-    float *ho = c->gru[i] + (size_t)cur * B * 512, *hn = c->gru[i] + (size_t)nxt * B * 512;
+    float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
     pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
     x = hn;
   }
-  const float *g1 = c->gru[0] + (size_t)nxt * B * 512, *g2 = c->gru[1] + (size_t)nxt * B * 512,
-              *g3 = c->gru[2] + (size_t)nxt * B * 512, *gb = c->gru[3] + (size_t)nxt * B * 512;
-  float *rbo = c->rb + (size_t)cur * B * 128, *rbn = c->rb + (size_t)nxt * B * 128;
+  const float *g1 = c->gru[0] + (size_t)nxt * Bp * 512, *g2 = c->gru[1] + (size_t)nxt * Bp * 512,
+              *g3 = c->gru[2] + (size_t)nxt * Bp * 512, *gb = c->gru[3] + (size_t)nxt * Bp * 512;
+  float *rbo = c->rb + (size_t)cur * Bp * 128, *rbn = c->rb + (size_t)nxt * Bp * 128;
   { Scope sc(c, KF_GRU_RB);   // input = [gru3 | conv2 out] (rnn.cpp:67-69)
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
@@ -436,15 +438,15 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
 //        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68].  Returns the byte count.
 extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long long max_bytes) {
   if (!c || !dst) return -1;
-  const size_t B = c->B;
+  const size_t B = c->B, Bp = c->Bp;
   const void *src = NULL; size_t n = 0;
   switch (which) {
-    case 0: src = c->feat; n = B * PN_FEAT_STRIDE * 4; break;
-    case 1: src = c->c1ring; n = 5 * B * 128 * 4; break;
-    case 2: src = c->c2ring; n = 3 * B * 512 * 4; break;
-    case 3: src = c->c2out; n = B * 512 * 4; break;
-    case 4: case 5: case 6: case 7: src = c->gru[which - 4]; n = 2 * B * 512 * 4; break;
-    case 8: src = c->rb; n = 2 * B * 128 * 4; break;
+    case 0: src = c->feat; n = Bp * PN_FEAT_STRIDE * 4; break;
+    case 1: src = c->c1ring; n = 5 * Bp * 128 * 4; break;
+    case 2: src = c->c2ring; n = 3 * Bp * 512 * 4; break;
+    case 3: src = c->c2out; n = Bp * 512 * 4; break;
+    case 4: case 5: case 6: case 7: src = c->gru[which - 4]; n = 2 * Bp * 512 * 4; break;
+    case 8: src = c->rb; n = 2 * Bp * 128 * 4; break;
     case 9: src = c->gr; n = B * 68 * 4; break;
     default: pn_set_error("bad debug buffer id"); return -1;
   }

@@ -28,6 +28,22 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define BK 32
 #define LDT 36            // padded LDS row stride (floats)
 #define NN_THREADS 256
+// timing experiments only (results become wrong): -DPN_EXP_NOBARRIER, -DPN_EXP_NOSTAGE, -DPN_EXP_NODRAIN
+#if defined(PN_EXP_NOSTAGE) || defined(PN_EXP_NOLOAD)
+#define PN_STAGE_LD(x) do {} while (0)
+#else
+#define PN_STAGE_LD(x) x
+#endif
+#if defined(PN_EXP_NOSTAGE) || defined(PN_EXP_NOSTASH)
+#define PN_STAGE_ST(x) do {} while (0)
+#else
+#define PN_STAGE_ST(x) x
+#endif
+#ifdef PN_EXP_NOBARRIER
+#define PN_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PN_SYNC() __syncthreads()
+#endif
 
 struct PnSegs {           // A operand = concatenation along K of up to 5 row-major panels
   const float *p[5];
@@ -38,6 +54,22 @@ struct PnSegs {           // A operand = concatenation along K of up to 5 row-ma
 };
 
 enum { ACT_LINEAR = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_RELU = 3 };
+
+// panel pointer by (uniform) index without dynamically indexing the by-value kernel argument
+// (a runtime index would spill the whole struct to scratch)
+#define PN_PANEL_ARGS const float *pp0, const float *pp1, const float *pp2, const float *pp3, const float *pp4, int pld
+#define PN_PANEL_PASS pp0, pp1, pp2, pp3, pp4, pld
+#define PN_PANEL_LOCALS(A) const float *pp0 = (A).p[0], *pp1 = (A).p[1], *pp2 = (A).p[2], *pp3 = (A).p[3], \
+                           *pp4 = (A).p[4]; const int pld = (A).ld[0]
+__device__ __forceinline__ const float *pn_seg_ptr(PN_PANEL_ARGS, int sg) {
+  (void)pld;
+  const float *p = pp0;
+  p = sg == 1 ? pp1 : p;
+  p = sg == 2 ? pp2 : p;
+  p = sg == 3 ? pp3 : p;
+  p = sg == 4 ? pp4 : p;
+  return p;
+}
 
 // tansig_approx / sigmoid_approx (reference vec.h:53-75)
 __device__ __forceinline__ float pn_tansig(float x, const float *tab) {
@@ -122,35 +154,46 @@ __global__ void pn_gru_strict_kernel(PnSegs X, const float *__restrict__ h_old, 
 
 // =============================== MFMA kernels ====================================================
 struct NnShared {
-  float A[BM][LDT];        // 18432 B
-  float B[4 * 32][LDT];    // 18432 B (up to 4 column tiles: dense NT<=4, GRU 3 gates)
+  float A[2][BM][LDT];       // 2 x 18432 B   double-buffered K-tiles
+  float B[2][4 * 32][LDT];   // 2 x 18432 B   (up to 4 column tiles: dense NT<=4, GRU 3 gates)
   float tansig[208];
 };
 
-// stage a 128 x 32 activation tile: rows m0.., columns k0..k0+31 of panel p (zero beyond
-// n_rows), k-interleaved into S.A.  Panels are padded to a multiple of 32 columns.
-__device__ __forceinline__ void pn_stage_A(float (*As)[LDT], const float *__restrict__ p, int ld, int k0,
-                                           int m0, int n_rows) {
+// ---- software-pipelined staging: global -> registers (issued before the MFMAs of the current
+// K-tile, so L2/HBM latency hides under them) -> LDS (written after them, into the other buffer).
+// A tile: 128 rows x 32 k of a row-major activation panel = 4 float4 per thread.  Every
+// activation buffer is allocated with its row count rounded up to 128 and its width to 32
+// (pn_context.cpp), so loads need no predication; only the final stores are row-guarded.
+__device__ __forceinline__ void pn_load_A(float4 (&ra)[4], const float *__restrict__ p, int ld, int k0, int m0) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int idx = tid + NN_THREADS * it;
     const int row = idx >> 3, c = idx & 7;        // 8 float4 per row
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + row < n_rows) v = *reinterpret_cast<const float4 *>(p + (size_t)(m0 + row) * ld + k0 + 4 * c);
-    // k_local = 4c + {0,1,2,3}: q = c>>1, (kh,s) = (0,2(c&1)), (1,2(c&1)), (0,2(c&1)+1), (1,2(c&1)+1)
-    float *dst = &As[row][(c >> 1) * 8 + 2 * (c & 1)];
-    *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
-    *reinterpret_cast<float2 *>(dst + 4) = make_float2(v.y, v.w);
+    ra[it] = *reinterpret_cast<const float4 *>(p + (size_t)(m0 + row) * ld + k0 + 4 * c);
   }
 }
-
-// stage one packed 32(col) x 32(k) weight tile (1024 contiguous floats, already k-interleaved)
-__device__ __forceinline__ void pn_stage_B(float (*Bs)[LDT], const float *__restrict__ tile) {
+// k-interleave while writing: k_local = 4c + {0,1,2,3} -> q = c>>1, (kh,s) = (0,2(c&1)), (1,2(c&1)),
+// (0,2(c&1)+1), (1,2(c&1)+1); position in the row = q*8 + kh*4 + s
+__device__ __forceinline__ void pn_store_A(float (*As)[LDT], const float4 (&ra)[4]) {
   const int tid = threadIdx.x;
-  const int j = tid >> 3, c = tid & 7;
-  const float4 v = *reinterpret_cast<const float4 *>(tile + j * 32 + 4 * c);
-  *reinterpret_cast<float4 *>(&Bs[j][4 * c]) = v;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int idx = tid + NN_THREADS * it;
+    const int row = idx >> 3, c = idx & 7;
+    float *dst = &As[row][(c >> 1) * 8 + 2 * (c & 1)];
+    *reinterpret_cast<float2 *>(dst) = make_float2(ra[it].x, ra[it].z);
+    *reinterpret_cast<float2 *>(dst + 4) = make_float2(ra[it].y, ra[it].w);
+  }
+}
+// one packed 32(col) x 32(k) weight tile = 1024 contiguous floats, already k-interleaved
+__device__ __forceinline__ float4 pn_load_B(const float *__restrict__ tile) {
+  const int tid = threadIdx.x;
+  return *reinterpret_cast<const float4 *>(tile + (tid >> 3) * 32 + 4 * (tid & 7));
+}
+__device__ __forceinline__ void pn_store_B(float (*Bs)[LDT], const float4 &v) {
+  const int tid = threadIdx.x;
+  *reinterpret_cast<float4 *>(&Bs[tid >> 3][4 * (tid & 7)]) = v;
 }
 
 // Toolchain hazard found on ROCm 7.2 / gfx950 (DESIGN.md "MFMA result hazard"): when a loop of
@@ -161,6 +204,9 @@ __device__ __forceinline__ void pn_stage_B(float (*Bs)[LDT], const float *__rest
 // copies.  Every K-tile therefore ends with an explicit drain of the matrix pipe (32 wait states
 // >= the 19 a 16-pass MFMA needs), pinned in place with scheduling barriers: ~1 % of a K-tile.
 __device__ __forceinline__ void pn_mfma_drain() {
+#ifdef PN_EXP_NODRAIN
+  return;
+#endif
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -170,6 +216,9 @@ template <int NT>
 __device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
                                              int wave, int lane) {
   const int r = lane & 31, kh = lane >> 5;
+  // keep the caller's prefetch (global loads of the NEXT K-tile) ahead of the MFMAs: without this
+  // hipcc sinks those loads below the MFMA block and their latency is exposed at the LDS write
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const float4 a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
@@ -197,8 +246,29 @@ __device__ __forceinline__ bool pn_tile_of_block(int n_mtiles, int n_ctiles, int
   return mt < n_mtiles;
 }
 
+// Register set holding one prefetched K-tile (A: 4 float4, B: up to NB float4 per thread)
+template <int NB> struct PnTileRegs { float4 a[4]; float4 b[NB]; };
+
+template <int NT>
+__device__ __forceinline__ void pn_dense_fetch(PnTileRegs<NT> &R, int g, int KT, int tps, PN_PANEL_ARGS,
+                                               const float *__restrict__ wbase, int m0) {
+  g = g < KT ? g : KT - 1;                     // past-the-end prefetches re-read the last tile (unused)
+  const int sg = g / tps, k0 = (g - sg * tps) * BK;
+  pn_load_A(R.a, pn_seg_ptr(PN_PANEL_PASS, sg), pld, k0, m0);
+#pragma unroll
+  for (int t = 0; t < NT; t++) R.b[t] = pn_load_B(wbase + ((size_t)t * KT + g) * 1024);
+}
+template <int NT>
+__device__ __forceinline__ void pn_tile_stash(float (*As)[LDT], float (*Bs)[LDT], const PnTileRegs<NT> &R) {
+  pn_store_A(As, R.a);
+#pragma unroll
+  for (int t = 0; t < NT; t++) pn_store_B(&Bs[32 * t], R.b[t]);
+}
+
 // Dense / conv-as-dense: out[m][n] = act(bias[n] + sum_k A[m][k] W[k][n]); Wp packed
 // [ctile][ktile][32 cols][32 k-interleaved]; NT column tiles per block.  tps = K-tiles per panel.
+// Pipeline: K-tile g is consumed from LDS buffer g&1 while tile g+1 waits in one register set and
+// the global loads of tile g+2 are issued into the other (two K-tiles of latency budget).
 template <int NT>
 __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
     PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
@@ -217,15 +287,25 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[t][i] = bv;
   }
+  const float *wbase = Wp + (size_t)(cb * NT) * KT * 1024;
+  PN_PANEL_LOCALS(A);
+  PnTileRegs<NT> R0, R1;
+  pn_dense_fetch<NT>(R0, 0, KT, tps, PN_PANEL_PASS, wbase, m0);
+  pn_dense_fetch<NT>(R1, 1, KT, tps, PN_PANEL_PASS, wbase, m0);
+  pn_tile_stash<NT>(S.A[0], S.B[0], R0);
+  __syncthreads();
 #pragma unroll 1
-  for (int kt = 0; kt < KT; kt++) {
-    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
+  for (int g = 0; g < KT; g += 2) {
+    pn_dense_fetch<NT>(R0, g + 2, KT, tps, PN_PANEL_PASS, wbase, m0);
+    pn_mma_ktile<NT>(S.A[0], S.B[0], acc, wave, lane);
+    pn_tile_stash<NT>(S.A[1], S.B[1], R1);
     __syncthreads();
-    pn_stage_A(S.A, A.p[sg], A.ld[sg], k0, m0, n_rows);
-#pragma unroll
-    for (int t = 0; t < NT; t++) pn_stage_B(&S.B[32 * t], Wp + ((size_t)(cb * NT + t) * KT + kt) * 1024);
-    __syncthreads();
-    pn_mma_ktile<NT>(S.A, S.B, acc, wave, lane);
+    if (g + 1 < KT) {
+      pn_dense_fetch<NT>(R1, g + 3, KT, tps, PN_PANEL_PASS, wbase, m0);
+      pn_mma_ktile<NT>(S.A[1], S.B[1], acc, wave, lane);
+      pn_tile_stash<NT>(S.A[0], S.B[0], R0);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -238,8 +318,16 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
   }
 }
 
-// Reset-after GRU step for a 128-stream x 32-neuron tile.
-// Wp: packed input weights  [3N/32 ctiles][KTx][32][32]; Up: packed recurrent [3N/32][N/32][32][32].
+// Reset-after GRU step for a 128-stream x 32-neuron tile, one software-pipelined sweep over the
+// tile schedule  g = 0 .. 2*KTx+KTh-1 :
+//   [0, KTx)          x tiles   z,r += W_{z,r} x              2 weight tiles / K-tile
+//   [KTx, KTx+KTh)    h tiles   z,r,tmp += U_{z,r,h} h_old    3 weight tiles / K-tile
+//   (gates: z,r = sigma(.), h = b_h + tmp*r)
+//   [KTx+KTh, end)    x tiles   h += W_h x                    1 weight tile  / K-tile
+// Tile g is consumed from LDS buffer g&1 while tile g+1 waits in a register set and tile g+2 is
+// in flight from L2/HBM; operand addresses are scalar selects of g, so the pipeline runs straight
+// through the phase boundaries (KTx and KTh are even).
+// Wp: packed input weights [3N/32 ctiles][KTx][32][32]; Up: packed recurrent [3N/32][N/32][32][32].
 // acc[0..3] = z, r, tmp (= b_rh + U_h h), h.
 __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
@@ -251,6 +339,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = mt * BM, KTh = N >> 5;
+  const int T1 = KTx, T2 = KTx + KTh, TT = 2 * KTx + KTh;
   const int col = nt * 32 + (lane & 31);
   if (tid < 201) S.tansig[tid] = tansig[tid];
 
@@ -262,26 +351,49 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = bt; }
   }
-  // z,r += W_{z,r} x
+  const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
+              *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
+  const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
+              *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
+  PN_PANEL_LOCALS(X);
+  PnTileRegs<3> R0, R1;
+#define GRU_FETCH(R, gg) do {                                                                              \
+    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
+    const bool p1_ = g_ < T1, p2_ = g_ >= T1 && g_ < T2;                                                   \
+    const int kx_ = p1_ ? g_ : (p2_ ? 0 : g_ - T2);      /* x-tile index (phases 1 and 3) */               \
+    const int kh_ = p2_ ? g_ - T1 : 0;                    /* h-tile index (phase 2) */                      \
+    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
+    pn_load_A((R).a, p2_ ? h_old : pn_seg_ptr(PN_PANEL_PASS, sg_), p2_ ? N : pld, p2_ ? kh_ * BK : k0_, m0);         \
+    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)kx_ * 1024 : (p2_ ? Uz + (size_t)kh_ * 1024 : Wh + (size_t)kx_ * 1024)); \
+    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)kx_ * 1024 : Ur + (size_t)kh_ * 1024);  /* unused in phase 3 */ \
+    (R).b[2] = pn_load_B(Uh + (size_t)kh_ * 1024);                                   /* phase 2 only */     \
+  } while (0)
+  GRU_FETCH(R0, 0); GRU_FETCH(R1, 1);
+  pn_tile_stash<3>(S.A[0], S.B[0], R0);
+  __syncthreads();
+  // ---- phase 1: z,r += W_{z,r} x ----------------------------------------------------------
 #pragma unroll 1
-  for (int kt = 0; kt < KTx; kt++) {
-    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
-    __syncthreads();
-    pn_stage_A(S.A, X.p[sg], X.ld[sg], k0, m0, n_rows);
-    pn_stage_B(&S.B[0], Wp + ((size_t)(0 * NTn + nt) * KTx + kt) * 1024);
-    pn_stage_B(&S.B[32], Wp + ((size_t)(1 * NTn + nt) * KTx + kt) * 1024);
-    __syncthreads();
-    pn_mma_ktile<2>(S.A, S.B, acc, wave, lane);
+  for (int g = 0; g < T1; g += 2) {
+    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
+    pn_mma_ktile<2>(S.A[0], S.B[0], acc, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
+    PN_SYNC();
+    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
+    pn_mma_ktile<2>(S.A[1], S.B[1], acc, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
+    PN_SYNC();
   }
-  // z,r,tmp += U_{z,r,h} h_old
+  // ---- phase 2: z,r,tmp += U_{z,r,h} h_old -------------------------------------------------
 #pragma unroll 1
-  for (int kt = 0; kt < KTh; kt++) {
-    __syncthreads();
-    pn_stage_A(S.A, h_old, N, kt * BK, m0, n_rows);
-#pragma unroll
-    for (int g = 0; g < 3; g++) pn_stage_B(&S.B[32 * g], Up + ((size_t)(g * NTn + nt) * KTh + kt) * 1024);
-    __syncthreads();
-    pn_mma_ktile<3>(S.A, S.B, acc, wave, lane);
+  for (int g = T1; g < T2; g += 2) {
+    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
+    pn_mma_ktile<3>(S.A[0], S.B[0], acc, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
+    PN_SYNC();
+    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
+    pn_mma_ktile<3>(S.A[1], S.B[1], acc, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
+    PN_SYNC();
   }
   // gates; h = b_h + tmp * r  (nnet.cpp:144,156,161-166)
   {
@@ -295,15 +407,17 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
       acc[3][i] = h;
     }
   }
-  // h += W_h x  (nnet.cpp:167)
+  // ---- phase 3: h += W_h x  (nnet.cpp:167) ---------------------------------------------------
 #pragma unroll 1
-  for (int kt = 0; kt < KTx; kt++) {
-    const int sg = kt / tps, k0 = (kt - sg * tps) * BK;
-    __syncthreads();
-    pn_stage_A(S.A, X.p[sg], X.ld[sg], k0, m0, n_rows);
-    pn_stage_B(&S.B[0], Wp + ((size_t)(2 * NTn + nt) * KTx + kt) * 1024);
-    __syncthreads();
-    pn_mma_ktile<1>(S.A, S.B, acc + 3, wave, lane);
+  for (int g = T2; g < TT; g += 2) {
+    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
+    pn_mma_ktile<1>(S.A[0], S.B[0], acc + 3, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
+    PN_SYNC();
+    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
+    pn_mma_ktile<1>(S.A[1], S.B[1], acc + 3, wave, lane);
+    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
+    PN_SYNC();
   }
   // activation + blend (nnet.cpp:175-179)
 #pragma unroll
@@ -316,6 +430,182 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
       h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
     }
   }
+#undef GRU_FETCH
+}
+
+// ---- large-batch GRU tile: 256 streams x 64 neurons per block (8 waves) ----------------------------
+// Same algorithm, schedule and numerics as pn_gru_mfma_kernel; the bigger tile halves the L2->LDS
+// operand traffic per FLOP (14 KB instead of 28 KB per 128x32x3-gate unit), which is what limited
+// the 128x32 kernel.  Waves: wm = wave&3 owns rows [64wm, 64wm+64) (two 32-row
+// MFMA tiles), wn = wave>>2 owns neuron tile 2*nb+wn.  acc[rt*4 + {z,r,tmp,h}].
+#define GL_THREADS 512
+#define GL_BM 256
+struct NnSharedL {
+  float A[2][GL_BM][LDT];       // 2 x 36864 B
+  float B[2][6 * 32][LDT];      // 2 x 27648 B   tiles (gate g, half wn) at index 2g + wn
+  float tansig[208];
+};
+
+// One K-tile of MFMAs for the large tile.  PF(q) is a hook after each quarter of the MFMAs; issuing
+// the prefetch there in four slices (pinned with sched_barriers) measured SLOWER (2.06 vs 1.89 ms:
+// the barriers stop hipcc hoisting the next quarter's ds_reads), so the prefetch stays one burst
+// in front of the MFMAs and PF is empty.
+#define PN_MMA_L(NG, AO, As_, Bs_, PF) do {                                                               \
+    const int r_ = lane & 31, kh_ = lane >> 5;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                        \
+      const float4 a0 = *reinterpret_cast<const float4 *>(&(As_)[64 * wm + r_][q * 8 + kh_ * 4]);          \
+      const float4 a1 = *reinterpret_cast<const float4 *>(&(As_)[64 * wm + 32 + r_][q * 8 + kh_ * 4]);     \
+      float4 bq[NG];                                                                                       \
+      _Pragma("unroll") for (int g = 0; g < NG; g++)                                                       \
+        bq[g] = *reinterpret_cast<const float4 *>(&(Bs_)[(2 * g + wn) * 32 + r_][q * 8 + kh_ * 4]);        \
+      PN_STEP_L(NG, AO, x) PN_STEP_L(NG, AO, y) PN_STEP_L(NG, AO, z) PN_STEP_L(NG, AO, w)                  \
+      PF(q);                                                                                               \
+    }                                                                                                      \
+    pn_mfma_drain();                                                                                       \
+  } while (0)
+#define PN_STEP_L(NG, AO, c)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                       \
+      acc[AO + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, bq[g].c, acc[AO + g], 0, 0, 0);            \
+      acc[4 + AO + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, bq[g].c, acc[4 + AO + g], 0, 0, 0);    \
+    }
+
+struct PnTileRegsL { float4 a[4]; float4 b[3]; };
+
+__global__ __launch_bounds__(GL_THREADS, 2) void pn_gru_mfma_l_kernel(
+    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
+    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
+    float *__restrict__ h_new, int n_rows, int n_mtiles) {
+  __shared__ NnSharedL S;
+  const int NTn = N >> 5, NB2 = N >> 6;         // 32-neuron tiles, 64-neuron blocks
+  int mt, nb;
+  if (!pn_tile_of_block(n_mtiles, NB2, mt, nb)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int m0 = mt * GL_BM, KTh = N >> 5;
+  const int T1 = KTx, T2 = KTx + KTh, TT = 2 * KTx + KTh;
+  const int col = (2 * nb + wn) * 32 + (lane & 31);
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+
+  floatx16 acc[8];
+  {
+    float bz = b[col]; bz += b[3 * N + col];
+    float br = b[N + col]; br += b[4 * N + col];
+    const float bt = b[5 * N + col];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      acc[0][i] = bz; acc[1][i] = br; acc[2][i] = bt;
+      acc[4][i] = bz; acc[5][i] = br; acc[6][i] = bt;
+    }
+  }
+  PN_PANEL_LOCALS(X);
+  // staging roles of this thread: A float4 #it -> row (tid + 512 it) >> 3; B float4 #j -> tile 2j + (tid >> 8)
+  const int brow = (tid & 255) >> 3, bc = tid & 7, bhalf = tid >> 8;      // tile (gate j, half bhalf)
+  const size_t wtile = (size_t)(2 * nb + bhalf);                           // 32-neuron tile this thread stages
+  PnTileRegsL R0, R1;
+  // prefetch of K-tile gg, split in a scalar setup + four slices q = 0..3 (A float4 #q, B float4 #q)
+  const float *pf_a; int pf_ld, pf_k; const float *pf_w0, *pf_w1, *pf_w2; bool pf_b1, pf_b2;
+#define GL_SETUP(gg) do {                                                                                    \
+    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                               \
+    const bool p1_ = g_ < T1, p2_ = g_ >= T1 && g_ < T2;                                                     \
+    const int kx_ = p1_ ? g_ : (p2_ ? 0 : g_ - T2), kh_ = p2_ ? g_ - T1 : 0;                                 \
+    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                                 \
+    pf_a = p2_ ? h_old : pn_seg_ptr(PN_PANEL_PASS, sg_);                                                     \
+    pf_ld = p2_ ? N : pld; pf_k = p2_ ? kh_ * BK : k0_;                                                      \
+    /* weight tile for gate j of the phase: phase1 j=0,1 -> Wp gates z,r; phase2 j=0..2 -> Up; phase3 j=0 -> Wp gate h */ \
+    pf_w0 = p2_ ? Up + ((size_t)(0 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024                         \
+                : Wp + ((size_t)((p1_ ? 0 : 2) * NTn) + wtile) * KTx * 1024 + (size_t)kx_ * 1024;             \
+    pf_w1 = p2_ ? Up + ((size_t)(1 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024                         \
+                : Wp + ((size_t)(1 * NTn) + wtile) * KTx * 1024 + (size_t)kx_ * 1024;                         \
+    pf_w2 = Up + ((size_t)(2 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024;                              \
+    pf_b1 = p1_ || p2_; pf_b2 = p2_;                                                                         \
+  } while (0)
+#define GL_SLICE(R, q) do {                                                                                  \
+    const int idx_ = tid + GL_THREADS * (q);                                                                 \
+    (R).a[q] = *reinterpret_cast<const float4 *>(pf_a + (size_t)(m0 + (idx_ >> 3)) * pf_ld + pf_k + 4 * (idx_ & 7)); \
+    if ((q) == 0) (R).b[0] = *reinterpret_cast<const float4 *>(pf_w0 + brow * 32 + 4 * bc);                  \
+    if ((q) == 1 && pf_b1) (R).b[1] = *reinterpret_cast<const float4 *>(pf_w1 + brow * 32 + 4 * bc);         \
+    if ((q) == 2 && pf_b2) (R).b[2] = *reinterpret_cast<const float4 *>(pf_w2 + brow * 32 + 4 * bc);         \
+  } while (0)
+#define GL_FETCH(R, gg) do { GL_SETUP(gg); GL_SLICE(R, 0); GL_SLICE(R, 1); GL_SLICE(R, 2); GL_SLICE(R, 3); } while (0)
+#define PF_NONE(q) do {} while (0)
+#define GL_STASH(R, buf) do {                                                                                \
+    _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                       \
+      const int idx_ = tid + GL_THREADS * it; const int row_ = idx_ >> 3, c_ = idx_ & 7;                     \
+      float *dst_ = &S.A[buf][row_][(c_ >> 1) * 8 + 2 * (c_ & 1)];                                           \
+      *reinterpret_cast<float2 *>(dst_) = make_float2((R).a[it].x, (R).a[it].z);                             \
+      *reinterpret_cast<float2 *>(dst_ + 4) = make_float2((R).a[it].y, (R).a[it].w);                         \
+    }                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 3; j++)                                                            \
+      *reinterpret_cast<float4 *>(&S.B[buf][(2 * j + bhalf) * 32 + brow][4 * bc]) = (R).b[j];                \
+  } while (0)
+  R0.b[1] = R0.b[2] = R1.b[1] = R1.b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  GL_FETCH(R0, 0); GL_FETCH(R1, 1);
+  GL_STASH(R0, 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < T1; g += 2) {
+    GL_FETCH(R0, g + 2);
+    PN_MMA_L(2, 0, S.A[0], S.B[0], PF_NONE);
+    GL_STASH(R1, 1);
+    __syncthreads();
+    GL_FETCH(R1, g + 3);
+    PN_MMA_L(2, 0, S.A[1], S.B[1], PF_NONE);
+    GL_STASH(R0, 0);
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int g = T1; g < T2; g += 2) {
+    GL_FETCH(R0, g + 2);
+    PN_MMA_L(3, 0, S.A[0], S.B[0], PF_NONE);
+    GL_STASH(R1, 1);
+    __syncthreads();
+    GL_FETCH(R1, g + 3);
+    PN_MMA_L(3, 0, S.A[1], S.B[1], PF_NONE);
+    GL_STASH(R0, 0);
+    __syncthreads();
+  }
+  {
+    const float bh = b[2 * N + col];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        acc[4 * rt + 0][i] = pn_sigmoid(acc[4 * rt + 0][i], S.tansig);
+        acc[4 * rt + 1][i] = pn_sigmoid(acc[4 * rt + 1][i], S.tansig);
+        float h = bh;
+        h += acc[4 * rt + 2][i] * acc[4 * rt + 1][i];
+        acc[4 * rt + 3][i] = h;
+      }
+  }
+#pragma unroll 1
+  for (int g = T2; g < TT; g += 2) {
+    GL_FETCH(R0, g + 2);
+    PN_MMA_L(1, 3, S.A[0], S.B[0], PF_NONE);
+    GL_STASH(R1, 1);
+    __syncthreads();
+    GL_FETCH(R1, g + 3);
+    PN_MMA_L(1, 3, S.A[1], S.B[1], PF_NONE);
+    GL_STASH(R0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + 64 * wm + 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (row < n_rows) {
+        const float hv = pn_act(acc[4 * rt + 3][i], act, S.tansig);
+        const float z = acc[4 * rt + 0][i];
+        const float ho = h_old[(size_t)row * N + col];
+        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
+      }
+    }
+#undef GL_FETCH
+#undef GL_STASH
+#undef GL_SETUP
+#undef GL_SLICE
+#undef PF_NONE
 }
 
 // ---- host: weight packing ---------------------------------------------------------------------
@@ -374,6 +664,13 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
     return;
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
+  if (n_rows >= 8192) {            // enough 256x64 tiles to fill the chip: the traffic-lean large tile
+    const int n_mt = (n_rows + GL_BM - 1) / GL_BM, NB2 = N / 64;
+    const int grid = 8 * ((n_mt + 7) / 8) * NB2;
+    hipLaunchKernelGGL(pn_gru_mfma_l_kernel, dim3(grid), dim3(GL_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps,
+                       act, tansig, h_new, n_rows, n_mt);
+    return;
+  }
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
   hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
