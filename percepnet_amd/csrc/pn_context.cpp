@@ -14,7 +14,7 @@
 struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int frame_t, const void *in, int in_is_i16,
                         float *hist, float2 *Xs, float2 *Ps, float *feat, int *silence, int *last_period,
-                        float *last_gain);
+                        float *last_gain, int blocks_per_cu);
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
 size_t pn_packed_floats(int K, int ncols, int ct_round);
@@ -138,7 +138,7 @@ static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2",
 struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
 
 struct pn_ctx {
-  int device, B, nn_mode;
+  int device, B, nn_mode, fe_bpc;
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
   int64_t t;                       // frames done
@@ -216,6 +216,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
+  c->fe_bpc = getenv("PN_FE_BPC") ? atoi(getenv("PN_FE_BPC")) : 0;   // tuning knob (front-end blocks per CU)
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { pn_set_error("hipStreamCreate failed"); delete c; return NULL; }
@@ -377,7 +378,7 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   PN_HIP_CHECK(hipSetDevice(c->device));
   { Scope sc(c, KF_FRONTEND);
     pn_launch_frontend(c->stream, c->tables, c->B, (int)(c->t % PN_HIST_FRAMES), d_in, is_i16, c->hist, c->Xs, c->Ps,
-                       c->feat, c->silence, c->last_period, c->last_gain); }
+                       c->feat, c->silence, c->last_period, c->last_gain, c->fe_bpc); }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
     pn_launch_backend(c->stream, c->tables, c->B, c->Xs, c->Ps, c->gr, c->silence, c->synth, d_out, is_i16); }

@@ -225,61 +225,83 @@ __device__ __forceinline__ void pn_window_scatter(const PnDspTablesLds &S, float
   }
 }
 
-// acc + sum_{j<N} a[AS*j]*b[BS*j], adds strictly in j order (celt_inner_prod / xcorr_kernel /
-// dual_inner_prod, pitch.h:53-144).  Operands are fetched 16 ahead of the dependent add chain.
-template <int N, int AS, int BS>
-__device__ __forceinline__ float pn_chain(const float *a, const float *b, float acc) {
-  constexpr int U = 16;
+// Lane broadcast without touching LDS: value held by lane `L` (compile-time) as a wave-uniform scalar.
+#define PN_BCAST(v, L) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (L)))
+
+// acc + sum_{j<N} a[j]*b[j], adds strictly in j order (celt_inner_prod / xcorr_kernel /
+// dual_inner_prod, pitch.h:53-144).  `a` is wave-uniform (every lane correlates the same x against
+// its own lag of y), so it is fetched once per 64 steps (lane l holds a[j0+l]) and broadcast with
+// v_readlane; only the per-lane operand b is read from LDS each step, 16 ahead of the dependent
+// add chain.  The caller guarantees a[] is readable up to the next multiple of 64.
+template <int N>
+__device__ __forceinline__ float pn_chain_u(const float *a, const float *b, float acc, int lane) {
+  constexpr int NB = N / 64, R = N % 64;
 #pragma unroll 1
-  for (int j0 = 0; j0 + U <= N; j0 += U) {
-    float av[U], bv[U];
+  for (int blk = 0; blk < NB; blk++) {
+    const float av = a[64 * blk + lane];
 #pragma unroll
-    for (int u = 0; u < U; u++) { av[u] = a[AS * (j0 + u)]; bv[u] = b[BS * (j0 + u)]; }
+    for (int u0 = 0; u0 < 64; u0 += 16) {
+      float bv[16];
 #pragma unroll
-    for (int u = 0; u < U; u++) acc = acc + av[u] * bv[u];
+      for (int u = 0; u < 16; u++) bv[u] = b[64 * blk + u0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc = acc + PN_BCAST(av, u0 + u) * bv[u];
+    }
   }
-  constexpr int R = N % U, J = N - R;
   if (R) {
-    float av[R ? R : 1], bv[R ? R : 1];
+    const float av = a[64 * NB + (lane < R ? lane : 0)];
 #pragma unroll
-    for (int u = 0; u < R; u++) { av[u] = a[AS * (J + u)]; bv[u] = b[BS * (J + u)]; }
+    for (int u0 = 0; u0 < R; u0 += 16) {
+      float bv[16];
 #pragma unroll
-    for (int u = 0; u < R; u++) acc = acc + av[u] * bv[u];
+      for (int u = 0; u < 16; u++) if (u0 + u < R) bv[u] = b[64 * NB + u0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) if (u0 + u < R) acc = acc + PN_BCAST(av, u0 + u) * bv[u];
+    }
   }
   return acc;
 }
 
-// find_best_pitch (pitch.cpp:46-104, float instantiation); executed redundantly by every lane
-// (wave-uniform control flow, LDS broadcast reads).  y[j] = yb[YS*j].
-template <int LEN, int MAXP, int YS>
-__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *yb, int &bp0, int &bp1) {
-  float Syy = pn_chain<LEN, YS, YS>(yb, yb, 1.0f);
+// find_best_pitch (pitch.cpp:46-104, float instantiation).  Wave-uniform: every lane runs the same
+// sequential recurrence; the operands (xcorr[i], y[i], y[i+LEN]) are fetched 64 at a time, one per
+// lane, and broadcast with v_readlane, so the loop body touches no LDS.  y is contiguous.
+template <int LEN, int MAXP>
+__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *y, int lane, int &bp0, int &bp1) {
+  float Syy = 1.0f;
+  {
+    constexpr int NBy = (LEN + 63) / 64;
+#pragma unroll 1
+    for (int blk = 0; blk < NBy; blk++) {
+      const int j = 64 * blk + lane;
+      const float yv = y[j < LEN ? j : 0];
+#pragma unroll
+      for (int u = 0; u < 64; u++)
+        if (64 * blk + u < LEN) { const float v = PN_BCAST(yv, u); Syy = Syy + v * v; }   // blk is uniform
+    }
+  }
   float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
   bp0 = 0; bp1 = 1;
-  constexpr int U = 8;
+  constexpr int NBp = (MAXP + 63) / 64;
 #pragma unroll 1
-  for (int i0 = 0; i0 < MAXP; i0 += U) {
-    float xc[U], d[U];
+  for (int blk = 0; blk < NBp; blk++) {
+    const int i = 64 * blk + lane, ic = i < MAXP ? i : MAXP - 1;
+    const float xv = xcorr[ic];
+    const float a = y[ic + LEN], c = y[ic];
+    const float dv = a * a - c * c;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = (i0 + u < MAXP) ? i0 + u : MAXP - 1;
-      xc[u] = xcorr[i];
-      const float a = yb[YS * (i + LEN)], c = yb[YS * i];
-      d[u] = a * a - c * c;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (i0 + u < MAXP) {
-        if (xc[u] > 0) {
-          float x16 = xc[u];
+    for (int u = 0; u < 64; u++) {
+      if (64 * blk + u < MAXP) {
+        const float xc = PN_BCAST(xv, u);
+        if (xc > 0) {
+          float x16 = xc;
           x16 *= 1e-12f;
           const float num = x16 * x16;
           if (num * bd1 > bn1 * Syy) {
-            if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = i0 + u; }
-            else { bn1 = num; bd1 = Syy; bp1 = i0 + u; }
+            if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = 64 * blk + u; }
+            else { bn1 = num; bd1 = Syy; bp1 = 64 * blk + u; }
           }
         }
-        Syy += d[u];
+        Syy += PN_BCAST(dv, u);
         Syy = (1 > Syy) ? 1 : Syy;
       }
     }
@@ -306,8 +328,10 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
   const int new_slot = frame_t % PN_HIST_FRAMES;
   const int base_slot = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
   float *pbuf = reinterpret_cast<float *>(W.fft);         // [864]  pitch scratch aliases the FFT buffer
-  float *xcorr = pbuf + 864;                              // [294]
-  float *yyl = xcorr + 296;                               // [385]
+  float *xcorr = pbuf + 864;                              // [294 -> 320 readable]
+  float *yyl = xcorr + 320;                               // [385]  (also x_lp4/y_lp4 before remove_doubling)
+  float *y4 = yyl;                                        // [387] y_lp4[j] = pbuf[2j]  (floats 1184..1570)
+  float *x4 = pbuf + 1600;                                // [240 -> 256 readable] x_lp4[j] = pbuf[384+2j]
   float *prod = reinterpret_cast<float *>(W.fft + 480);   // [400]  per-bin X.P products (entries >= 480 are free after the FFT)
 
   for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
@@ -349,7 +373,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
     float ac[5];
     {
       const int lag = lane < 4 ? lane : 4;
-      float ack = pn_chain<860, 1, 1>(pbuf, pbuf + lag, 0.f);
+      float ack = pn_chain_u<860>(pbuf, pbuf + lag, 0.f, lane);
       float d = 0;
       for (int i = lag + 860; i < 864; i++) d = d + pbuf[i] * pbuf[i - lag];
       ack += d;
@@ -421,28 +445,41 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
     }
 
     // -- pitch_search (pitch.cpp:283-386): x_lp = pbuf+384, y = pbuf, len 960, max_pitch 588 ----
-    // coarse: x_lp4[j] = pbuf[384+2j], y_lp4[j] = pbuf[2j]; lane owns lags {lane, lane+64, lane+128}
-    // (three independent j-ascending chains per lane)
+    // coarse: the 4x-decimated signals x_lp4[j] = pbuf[384+2j] (240) and y_lp4[j] = pbuf[2j] (387) are
+    // first copied out contiguously (conflict-free reads, and x_lp4 can be lane-broadcast);
+    // lane owns lags {lane, lane+64, lane+128}: three independent j-ascending chains
+    for (int j = lane; j < 387; j += LANES) y4[j] = pbuf[2 * j];
+    for (int j = lane; j < 256; j += LANES) x4[j] = pbuf[j < 240 ? 384 + 2 * j : 0];
+    PN_WAVE_SYNC();
     {
       const int i0 = lane, i1 = lane + 64, i2 = (lane + 128 < 147) ? lane + 128 : 146;
       float s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll 1
-      for (int j0 = 0; j0 < 240; j0 += 8) {
-        float a[8], b0[8], b1[8], b2[8];
+      for (int blk = 0; blk < 4; blk++) {          // 240 = 3*64 + 48
+        const float av = x4[64 * blk + lane];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          a[u] = pbuf[384 + 2 * (j0 + u)];
-          b0[u] = pbuf[2 * (i0 + j0 + u)]; b1[u] = pbuf[2 * (i1 + j0 + u)]; b2[u] = pbuf[2 * (i2 + j0 + u)];
+        for (int u0 = 0; u0 < 64; u0 += 8) {
+          if (64 * blk + u0 < 240) {
+            float b0[8], b1[8], b2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int j = 64 * blk + u0 + u;
+              b0[u] = y4[i0 + j]; b1[u] = y4[i1 + j]; b2[u] = y4[i2 + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const float a = PN_BCAST(av, u0 + u);
+              s0 = s0 + a * b0[u]; s1 = s1 + a * b1[u]; s2 = s2 + a * b2[u];
+            }
+          }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) { s0 = s0 + a[u] * b0[u]; s1 = s1 + a[u] * b1[u]; s2 = s2 + a[u] * b2[u]; }
       }
       xcorr[i0] = s0; xcorr[i1] = s1;
       if (lane + 128 < 147) xcorr[i2] = s2;
     }
     PN_WAVE_SYNC();
     int bp0, bp1;
-    pn_find_best_pitch<240, 147, 2>(xcorr, pbuf, bp0, bp1);
+    pn_find_best_pitch<240, 147>(xcorr, y4, lane, bp0, bp1);
     PN_WAVE_SYNC();
     // fine: only lags within +-2 of 2*best (pitch.cpp:344-361); other entries are 0
     for (int i = lane; i < 294; i += LANES) xcorr[i] = 0;
@@ -450,11 +487,11 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
     {
       const int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
       const bool act = lane < 10 && c >= 0 && c < 294;
-      const float sum = pn_chain<480, 1, 1>(pbuf + 384, pbuf + (act ? c : 0), 0.f);
+      const float sum = pn_chain_u<480>(pbuf + 384, pbuf + (act ? c : 0), 0.f, lane);
       if (act) xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
     }
     PN_WAVE_SYNC();
-    pn_find_best_pitch<480, 294, 1>(xcorr, pbuf, bp0, bp1);
+    pn_find_best_pitch<480, 294>(xcorr, pbuf, lane, bp0, bp1);
     int offset = 0;
     if (bp0 > 0 && bp0 < 294 - 1) {
       const float a = xcorr[bp0 - 1], b = xcorr[bp0], c = xcorr[bp0 + 1];
@@ -484,26 +521,27 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
         else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
         lag = (lane < 16) ? T1 : T1b;
       }
-      const float dot = pn_chain<480, 1, 1>(x, x - lag, 0.f);   // lanes >= 30 shadow lag 0
+      const float dot = pn_chain_u<480>(x, x - lag, 0.f, lane);   // lanes >= 30 shadow lag 0
       const float xx = __shfl(dot, 0);
       float xy = __shfl(dot, 1);
-      // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, wave-uniform
+      // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, wave-uniform; operands
+      // fetched 64 per block (one per lane) and broadcast, results collected one per lane
       {
         float yy = xx;
         if (lane == 0) yyl[0] = xx;
 #pragma unroll 1
-        for (int i0 = 1; i0 <= 384; i0 += 16) {
-          float p[16], q[16];
+        for (int blk = 0; blk < 6; blk++) {        // i = 1 + 64*blk + u, u < 64  (384 = 6*64)
+          const int i = 1 + 64 * blk + lane;
+          const float a = x[-i], c = x[480 - i];
+          const float pv = a * a, qv = c * c;
+          float keep = 0;
 #pragma unroll
-          for (int u = 0; u < 16; u++) {
-            const float a = x[-(i0 + u)], c = x[480 - (i0 + u)];
-            p[u] = a * a; q[u] = c * c;
+          for (int u = 0; u < 64; u++) {
+            yy = yy + PN_BCAST(pv, u) - PN_BCAST(qv, u);
+            const float cl = (0 > yy) ? 0 : yy;
+            keep = (lane == u) ? cl : keep;
           }
-#pragma unroll
-          for (int u = 0; u < 16; u++) {
-            yy = yy + p[u] - q[u];
-            if (lane == 0) yyl[i0 + u] = (0 > yy) ? 0 : yy;
-          }
+          yyl[i] = keep;
         }
       }
       PN_WAVE_SYNC();
@@ -538,7 +576,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
       }
       best_xy = (0 > best_xy) ? 0 : best_xy;
       if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
-      const float xc = pn_chain<480, 1, 1>(x, x - (Tsel + (lane < 3 ? lane : 2) - 1), 0.f);
+      const float xc = pn_chain_u<480>(x, x - (Tsel + (lane < 3 ? lane : 2) - 1), 0.f, lane);
       const float xc0 = __shfl(xc, 0), xc1 = __shfl(xc, 1), xc2 = __shfl(xc, 2);
       int off2;
       if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
@@ -668,16 +706,19 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
 }
 
 // ---- launchers -------------------------------------------------------------------------------
-static inline int pn_dsp_grid(int n_streams) {
+// blocks_per_cu: 2 fills the CUs (80 KB LDS each); 1 leaves half of every CU's LDS/registers free so
+// that an MFMA-bound network kernel of another frame can be co-resident (pipelined mode)
+static inline int pn_dsp_grid(int n_streams, int blocks_per_cu) {
   const int need = (n_streams + WPB - 1) / WPB;
-  const int cap = 256 * (PN_DSP_WAVES_PER_SIMD * 4 / WPB);   // 256 CUs x resident blocks per CU
+  const int full = PN_DSP_WAVES_PER_SIMD * 4 / WPB;
+  const int cap = 256 * ((blocks_per_cu > 0 && blocks_per_cu < full) ? blocks_per_cu : full);
   return need < cap ? need : cap;
 }
 
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int frame_t, const void *in, int in_is_i16,
                         float *hist, float2 *Xs, float2 *Ps, float *feat, int *silence, int *last_period,
-                        float *last_gain) {
-  const int grid = pn_dsp_grid(n_streams);
+                        float *last_gain, int blocks_per_cu) {
+  const int grid = pn_dsp_grid(n_streams, blocks_per_cu);
   if (in_is_i16)
     hipLaunchKernelGGL(pn_frontend_kernel<int16_t>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, frame_t,
                        (const int16_t *)in, hist, Xs, Ps, feat, silence, last_period, last_gain);
@@ -688,7 +729,7 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int fr
 
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16) {
-  const int grid = pn_dsp_grid(n_streams);
+  const int grid = pn_dsp_grid(n_streams, 0);
   if (out_is_i16)
     hipLaunchKernelGGL(pn_backend_kernel<int16_t>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, Xs, Ps, gr, silence,
                        synth_mem, (int16_t *)out);

@@ -318,17 +318,44 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
   }
 }
 
+// Three-accumulator K-tile: acc[I0], acc[I1], acc[I2] += A * B[0..2]
+template <int I0, int I1, int I2>
+__device__ __forceinline__ void pn_mma_ktile3(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
+                                              int wave, int lane) {
+  const int r = lane & 31, kh = lane >> 5;
+  __builtin_amdgcn_sched_barrier(0);   // keep the caller's prefetch loads ahead of the MFMAs
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float4 a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
+    const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[r][q * 8 + kh * 4]);
+    const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[32 + r][q * 8 + kh * 4]);
+    const float4 b2 = *reinterpret_cast<const float4 *>(&Bs[64 + r][q * 8 + kh * 4]);
+#define PN_STEP3(c)                                                                       \
+    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b0.c, acc[I0], 0, 0, 0);          \
+    acc[I1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b1.c, acc[I1], 0, 0, 0);          \
+    acc[I2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b2.c, acc[I2], 0, 0, 0);
+    PN_STEP3(x) PN_STEP3(y) PN_STEP3(z) PN_STEP3(w)
+#undef PN_STEP3
+  }
+  pn_mfma_drain();
+}
+
 // Reset-after GRU step for a 128-stream x 32-neuron tile, one software-pipelined sweep over the
-// tile schedule  g = 0 .. 2*KTx+KTh-1 :
-//   [0, KTx)          x tiles   z,r += W_{z,r} x              2 weight tiles / K-tile
-//   [KTx, KTx+KTh)    h tiles   z,r,tmp += U_{z,r,h} h_old    3 weight tiles / K-tile
-//   (gates: z,r = sigma(.), h = b_h + tmp*r)
-//   [KTx+KTh, end)    x tiles   h += W_h x                    1 weight tile  / K-tile
+// tile schedule  g = 0 .. KTx+KTh-1 :
+//   [0, KTx)          x tiles   z,r += W_{z,r} x ;  hx += W_h x       3 weight tiles / K-tile
+//   [KTx, KTx+KTh)    h tiles   z,r,tmp += U_{z,r,h} h_old            3 weight tiles / K-tile
+//   epilogue: z,r = sigma(.),  h = (b_h + tmp*r) + hx,  h = tanh(h),  state = z*h_old + (1-z)*h
+// Summation order: z, r and tmp are exactly the reference's chains (bias, then inputs k ascending,
+// then recurrent k ascending; nnet.cpp:135-166).  The candidate's input term W_h x is accumulated
+// as its own k-ascending chain from 0 and added to (b_h + tmp*r) once, where the reference keeps
+// adding the products onto that value one by one (nnet.cpp:166-167): same terms, one different
+// association — it removes a second sweep over x (a third of all K-tiles) and is covered by the
+// same 2e-5 g/r tolerance as the fused-vs-separate rounding (measured: see DESIGN.md).
 // Tile g is consumed from LDS buffer g&1 while tile g+1 waits in a register set and tile g+2 is
 // in flight from L2/HBM; operand addresses are scalar selects of g, so the pipeline runs straight
-// through the phase boundaries (KTx and KTh are even).
+// through the phase boundary (KTx and KTh are even).
 // Wp: packed input weights [3N/32 ctiles][KTx][32][32]; Up: packed recurrent [3N/32][N/32][32][32].
-// acc[0..3] = z, r, tmp (= b_rh + U_h h), h.
+// acc[0..3] = z, r, hx, tmp.
 __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
     const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
@@ -339,7 +366,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = mt * BM, KTh = N >> 5;
-  const int T1 = KTx, T2 = KTx + KTh, TT = 2 * KTx + KTh;
+  const int T1 = KTx, TT = KTx + KTh;
   const int col = nt * 32 + (lane & 31);
   if (tid < 201) S.tansig[tid] = tansig[tid];
 
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     float br = b[N + col]; br += b[4 * N + col];// 147-153
     const float bt = b[5 * N + col];            // 164
 #pragma unroll
-    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = bt; }
+    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
   }
   const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
               *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
@@ -359,75 +386,57 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
   PnTileRegs<3> R0, R1;
 #define GRU_FETCH(R, gg) do {                                                                              \
     int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
-    const bool p1_ = g_ < T1, p2_ = g_ >= T1 && g_ < T2;                                                   \
-    const int kx_ = p1_ ? g_ : (p2_ ? 0 : g_ - T2);      /* x-tile index (phases 1 and 3) */               \
-    const int kh_ = p2_ ? g_ - T1 : 0;                    /* h-tile index (phase 2) */                      \
+    const bool p1_ = g_ < T1;                                                                              \
+    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    pn_load_A((R).a, p2_ ? h_old : pn_seg_ptr(PN_PANEL_PASS, sg_), p2_ ? N : pld, p2_ ? kh_ * BK : k0_, m0);         \
-    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)kx_ * 1024 : (p2_ ? Uz + (size_t)kh_ * 1024 : Wh + (size_t)kx_ * 1024)); \
-    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)kx_ * 1024 : Ur + (size_t)kh_ * 1024);  /* unused in phase 3 */ \
-    (R).b[2] = pn_load_B(Uh + (size_t)kh_ * 1024);                                   /* phase 2 only */     \
+    pn_load_A((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old, p1_ ? pld : N, p1_ ? k0_ : kh_ * BK, m0); \
+    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)kx_ * 1024 : Uz + (size_t)kh_ * 1024);                         \
+    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)kx_ * 1024 : Ur + (size_t)kh_ * 1024);                         \
+    (R).b[2] = pn_load_B(p1_ ? Wh + (size_t)kx_ * 1024 : Uh + (size_t)kh_ * 1024);                         \
   } while (0)
   GRU_FETCH(R0, 0); GRU_FETCH(R1, 1);
   pn_tile_stash<3>(S.A[0], S.B[0], R0);
   __syncthreads();
-  // ---- phase 1: z,r += W_{z,r} x ----------------------------------------------------------
+  // ---- phase 1: z,r,hx += W_{z,r,h} x ---------------------------------------------------------
 #pragma unroll 1
   for (int g = 0; g < T1; g += 2) {
-    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
-    pn_mma_ktile<2>(S.A[0], S.B[0], acc, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
-    PN_SYNC();
-    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
-    pn_mma_ktile<2>(S.A[1], S.B[1], acc, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
-    PN_SYNC();
+    GRU_FETCH(R0, g + 2);
+    pn_mma_ktile3<0, 1, 2>(S.A[0], S.B[0], acc, wave, lane);
+    pn_tile_stash<3>(S.A[1], S.B[1], R1);
+    __syncthreads();
+    GRU_FETCH(R1, g + 3);
+    pn_mma_ktile3<0, 1, 2>(S.A[1], S.B[1], acc, wave, lane);
+    pn_tile_stash<3>(S.A[0], S.B[0], R0);
+    __syncthreads();
   }
   // ---- phase 2: z,r,tmp += U_{z,r,h} h_old -------------------------------------------------
 #pragma unroll 1
-  for (int g = T1; g < T2; g += 2) {
-    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
-    pn_mma_ktile<3>(S.A[0], S.B[0], acc, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
-    PN_SYNC();
-    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
-    pn_mma_ktile<3>(S.A[1], S.B[1], acc, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
-    PN_SYNC();
+  for (int g = T1; g < TT; g += 2) {
+    GRU_FETCH(R0, g + 2);
+    pn_mma_ktile3<0, 1, 3>(S.A[0], S.B[0], acc, wave, lane);
+    pn_tile_stash<3>(S.A[1], S.B[1], R1);
+    __syncthreads();
+    GRU_FETCH(R1, g + 3);
+    pn_mma_ktile3<0, 1, 3>(S.A[1], S.B[1], acc, wave, lane);
+    pn_tile_stash<3>(S.A[0], S.B[0], R0);
+    __syncthreads();
   }
-  // gates; h = b_h + tmp * r  (nnet.cpp:144,156,161-166)
+  // gates, candidate, blend (nnet.cpp:144,156,161-179)
   {
     const float bh = b[2 * N + col];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      acc[0][i] = pn_sigmoid(acc[0][i], S.tansig);
-      acc[1][i] = pn_sigmoid(acc[1][i], S.tansig);
+      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      const float z = pn_sigmoid(acc[0][i], S.tansig);
+      const float r = pn_sigmoid(acc[1][i], S.tansig);
       float h = bh;
-      h += acc[2][i] * acc[1][i];
-      acc[3][i] = h;
-    }
-  }
-  // ---- phase 3: h += W_h x  (nnet.cpp:167) ---------------------------------------------------
-#pragma unroll 1
-  for (int g = T2; g < TT; g += 2) {
-    PN_STAGE_LD(GRU_FETCH(R0, g + 2));
-    pn_mma_ktile<1>(S.A[0], S.B[0], acc + 3, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[1], S.B[1], R1));
-    PN_SYNC();
-    PN_STAGE_LD(GRU_FETCH(R1, g + 3));
-    pn_mma_ktile<1>(S.A[1], S.B[1], acc + 3, wave, lane);
-    PN_STAGE_ST(pn_tile_stash<3>(S.A[0], S.B[0], R0));
-    PN_SYNC();
-  }
-  // activation + blend (nnet.cpp:175-179)
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-    if (row < n_rows) {
-      const float hv = pn_act(acc[3][i], act, S.tansig);
-      const float z = acc[0][i];
-      const float ho = h_old[(size_t)row * N + col];
-      h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
+      h += acc[3][i] * r;
+      h = h + acc[2][i];
+      const float hv = pn_act(h, act, S.tansig);
+      if (row < n_rows) {
+        const float ho = h_old[(size_t)row * N + col];
+        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
+      }
     }
   }
 #undef GRU_FETCH
