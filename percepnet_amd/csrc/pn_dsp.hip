@@ -44,7 +44,7 @@
 // same-wave global-memory store -> load ordering (drains vmcnt)
 #define PN_WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-struct PnDspTablesLds {
+struct alignas(16) PnDspTablesLds {
   float2 tw[PN_NFFT];            // 7680 B
   float win[PN_FRAME];           // 1920 B
   float frac[PN_SPEC_BINS];      // 1600 B
@@ -53,9 +53,9 @@ struct PnDspTablesLds {
   uint8_t band[PN_SPEC_BINS];
   float comb_w[8];
 };
-struct PnDspWaveLds {
+struct alignas(16) PnDspWaveLds {
   float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
-  float e[4][PN_NB + 2];
+  float e[4][PN_NB + 2];         // 576 B
 };
 struct PnDspShared {
   PnDspTablesLds t;
@@ -225,87 +225,107 @@ __device__ __forceinline__ void pn_window_scatter(const PnDspTablesLds &S, float
   }
 }
 
-// Lane broadcast without touching LDS: value held by lane `L` (compile-time) as a wave-uniform scalar.
-#define PN_BCAST(v, L) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (L)))
-
 // acc + sum_{j<N} a[j]*b[j], adds strictly in j order (celt_inner_prod / xcorr_kernel /
 // dual_inner_prod, pitch.h:53-144).  `a` is wave-uniform (every lane correlates the same x against
-// its own lag of y), so it is fetched once per 64 steps (lane l holds a[j0+l]) and broadcast with
-// v_readlane; only the per-lane operand b is read from LDS each step, 16 ahead of the dependent
-// add chain.  The caller guarantees a[] is readable up to the next multiple of 64.
+// its own lag of y): it is read with ds_read_b128 at one address for all lanes (an LDS broadcast,
+// one instruction per 4 steps, `a` must be 16-byte aligned); the per-lane operand b costs one
+// ds_read_b32 per step.  Operands are fetched 16 steps ahead of the dependent add chain; only the
+// adds are serially dependent.  N must be a multiple of 4.
 template <int N>
-__device__ __forceinline__ float pn_chain_u(const float *a, const float *b, float acc, int lane) {
-  constexpr int NB = N / 64, R = N % 64;
+__device__ __forceinline__ float pn_chain_u(const float *a, const float *b, float acc) {
+  constexpr int U = 16, NF = N / U, R = N % U;
 #pragma unroll 1
-  for (int blk = 0; blk < NB; blk++) {
-    const float av = a[64 * blk + lane];
+  for (int blk = 0; blk < NF; blk++) {
+    float4 av[4]; float bv[U];
 #pragma unroll
-    for (int u0 = 0; u0 < 64; u0 += 16) {
-      float bv[16];
+    for (int v = 0; v < 4; v++) av[v] = *reinterpret_cast<const float4 *>(a + U * blk + 4 * v);
 #pragma unroll
-      for (int u = 0; u < 16; u++) bv[u] = b[64 * blk + u0 + u];
+    for (int u = 0; u < U; u++) bv[u] = b[U * blk + u];
 #pragma unroll
-      for (int u = 0; u < 16; u++) acc = acc + PN_BCAST(av, u0 + u) * bv[u];
+    for (int v = 0; v < 4; v++) {
+      acc = acc + av[v].x * bv[4 * v]; acc = acc + av[v].y * bv[4 * v + 1];
+      acc = acc + av[v].z * bv[4 * v + 2]; acc = acc + av[v].w * bv[4 * v + 3];
     }
   }
   if (R) {
-    const float av = a[64 * NB + (lane < R ? lane : 0)];
+    float4 av[R / 4 ? R / 4 : 1]; float bv[R ? R : 1];
 #pragma unroll
-    for (int u0 = 0; u0 < R; u0 += 16) {
-      float bv[16];
+    for (int v = 0; v < R / 4; v++) av[v] = *reinterpret_cast<const float4 *>(a + U * NF + 4 * v);
 #pragma unroll
-      for (int u = 0; u < 16; u++) if (u0 + u < R) bv[u] = b[64 * NB + u0 + u];
+    for (int u = 0; u < R; u++) bv[u] = b[U * NF + u];
 #pragma unroll
-      for (int u = 0; u < 16; u++) if (u0 + u < R) acc = acc + PN_BCAST(av, u0 + u) * bv[u];
+    for (int v = 0; v < R / 4; v++) {
+      acc = acc + av[v].x * bv[4 * v]; acc = acc + av[v].y * bv[4 * v + 1];
+      acc = acc + av[v].z * bv[4 * v + 2]; acc = acc + av[v].w * bv[4 * v + 3];
     }
   }
   return acc;
 }
 
-// find_best_pitch (pitch.cpp:46-104, float instantiation).  Wave-uniform: every lane runs the same
-// sequential recurrence; the operands (xcorr[i], y[i], y[i+LEN]) are fetched 64 at a time, one per
-// lane, and broadcast with v_readlane, so the loop body touches no LDS.  y is contiguous.
+// find_best_pitch (pitch.cpp:46-104, float instantiation).  Wave-uniform recurrence: every lane
+// runs the same sequential loop on LDS-broadcast operands.  The squares y[j]^2 and the window
+// updates d[i] = y[i+LEN]^2 - y[i]^2 are formed lane-parallel first (same roundings) into `scr`
+// (>= max(LEN rounded up to 64... see callers) so the serial loops are one add (resp. add + max +
+// compare) per step.  xcorr, y, scr 16-byte aligned; MAXP, LEN multiples of... any.
 template <int LEN, int MAXP>
-__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *y, int lane, int &bp0, int &bp1) {
-  float Syy = 1.0f;
-  {
-    constexpr int NBy = (LEN + 63) / 64;
-#pragma unroll 1
-    for (int blk = 0; blk < NBy; blk++) {
-      const int j = 64 * blk + lane;
-      const float yv = y[j < LEN ? j : 0];
-#pragma unroll
-      for (int u = 0; u < 64; u++)
-        if (64 * blk + u < LEN) { const float v = PN_BCAST(yv, u); Syy = Syy + v * v; }   // blk is uniform
-    }
-  }
-  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-  bp0 = 0; bp1 = 1;
-  constexpr int NBp = (MAXP + 63) / 64;
-#pragma unroll 1
-  for (int blk = 0; blk < NBp; blk++) {
-    const int i = 64 * blk + lane, ic = i < MAXP ? i : MAXP - 1;
-    const float xv = xcorr[ic];
+__device__ __forceinline__ void pn_find_best_pitch(const float *xcorr, const float *y, float *sq /*[64]*/,
+                                                   float *d /*[MAXP rounded up to 4]*/, int lane, int &bp0, int &bp1) {
+  // d[i] = y[i+LEN]*y[i+LEN] - y[i]*y[i]
+  for (int i = lane; i < ((MAXP + 3) & ~3); i += LANES) {
+    const int ic = i < MAXP ? i : MAXP - 1;
     const float a = y[ic + LEN], c = y[ic];
-    const float dv = a * a - c * c;
+    d[i] = a * a - c * c;
+  }
+  float Syy = 1.0f;
+  constexpr int NBy = (LEN + 63) / 64;
+#pragma unroll 1
+  for (int blk = 0; blk < NBy; blk++) {
+    const int j = 64 * blk + lane;
+    const float yv = y[j < LEN ? j : 0];
+    PN_WAVE_SYNC();
+    sq[lane] = yv * yv;
+    PN_WAVE_SYNC();
 #pragma unroll
-    for (int u = 0; u < 64; u++) {
-      if (64 * blk + u < MAXP) {
-        const float xc = PN_BCAST(xv, u);
-        if (xc > 0) {
-          float x16 = xc;
-          x16 *= 1e-12f;
-          const float num = x16 * x16;
-          if (num * bd1 > bn1 * Syy) {
-            if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = 64 * blk + u; }
-            else { bn1 = num; bd1 = Syy; bp1 = 64 * blk + u; }
-          }
-        }
-        Syy += PN_BCAST(dv, u);
-        Syy = (1 > Syy) ? 1 : Syy;
+    for (int v = 0; v < 16; v++) {
+      if (64 * blk + 4 * v < LEN) {           // LEN is a multiple of 4; blk uniform
+        const float4 q = *reinterpret_cast<const float4 *>(sq + 4 * v);
+        Syy = Syy + q.x; Syy = Syy + q.y; Syy = Syy + q.z; Syy = Syy + q.w;
       }
     }
   }
+  PN_WAVE_SYNC();
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  bp0 = 0; bp1 = 1;
+#define PN_FBP_STEP(xc_, dd_, idx_)                                                                  \
+  if ((idx_) < MAXP) {                                                                              \
+    if ((xc_) > 0) {                                                                                \
+      float x16 = (xc_);                                                                            \
+      x16 *= 1e-12f;                                                                                \
+      const float num = x16 * x16;                                                                  \
+      if (num * bd1 > bn1 * Syy) {                                                                  \
+        if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = (idx_); } \
+        else { bn1 = num; bd1 = Syy; bp1 = (idx_); }                                                \
+      }                                                                                             \
+    }                                                                                               \
+    Syy += (dd_);                                                                                   \
+    Syy = (1 > Syy) ? 1 : Syy;                                                                      \
+  }
+#pragma unroll 1
+  for (int i0 = 0; i0 < MAXP; i0 += 16) {
+    float4 xv[4], dv[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = (i0 + 4 * v < ((MAXP + 3) & ~3)) ? i0 + 4 * v : 0;
+      xv[v] = *reinterpret_cast<const float4 *>(xcorr + i);
+      dv[v] = *reinterpret_cast<const float4 *>(d + i);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      PN_FBP_STEP(xv[v].x, dv[v].x, i0 + 4 * v) PN_FBP_STEP(xv[v].y, dv[v].y, i0 + 4 * v + 1)
+      PN_FBP_STEP(xv[v].z, dv[v].z, i0 + 4 * v + 2) PN_FBP_STEP(xv[v].w, dv[v].w, i0 + 4 * v + 3)
+    }
+  }
+#undef PN_FBP_STEP
 }
 
 __device__ __forceinline__ float pn_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
@@ -328,10 +348,12 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
   const int new_slot = frame_t % PN_HIST_FRAMES;
   const int base_slot = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
   float *pbuf = reinterpret_cast<float *>(W.fft);         // [864]  pitch scratch aliases the FFT buffer
-  float *xcorr = pbuf + 864;                              // [294 -> 320 readable]
-  float *yyl = xcorr + 320;                               // [385]  (also x_lp4/y_lp4 before remove_doubling)
-  float *y4 = yyl;                                        // [387] y_lp4[j] = pbuf[2j]  (floats 1184..1570)
-  float *x4 = pbuf + 1600;                                // [240 -> 256 readable] x_lp4[j] = pbuf[384+2j]
+  // float offsets inside the wave's 1920-float buffer (all 16-byte aligned where b128-read):
+  float *xcorr = pbuf + 864;                              // [ 864,1184) xcorr[294] (+pad); later p/q scratch of yy_lookup
+  float *y4 = pbuf + 1184;                                // [1184,1571) y_lp4[387] = pbuf[2j]; later d[] of the fine pass
+  float *yyl = pbuf + 1187;                               // [1187,1572) yy_lookup[385], &yyl[1] is 16-byte aligned
+  float *x4 = pbuf + 1600;                                // [1600,1856) x_lp4[240] (+pad) = pbuf[384+2j]; later d[] of the coarse pass
+  float *sq64 = pbuf + 1856;                              // [1856,1920) 64-float broadcast scratch
   float *prod = reinterpret_cast<float *>(W.fft + 480);   // [400]  per-bin X.P products (entries >= 480 are free after the FFT)
 
   for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
     float ac[5];
     {
       const int lag = lane < 4 ? lane : 4;
-      float ack = pn_chain_u<860>(pbuf, pbuf + lag, 0.f, lane);
+      float ack = pn_chain_u<860>(pbuf, pbuf + lag, 0.f);
       float d = 0;
       for (int i = lag + 860; i < 864; i++) d = d + pbuf[i] * pbuf[i - lag];
       ack += d;
@@ -455,31 +477,21 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
       const int i0 = lane, i1 = lane + 64, i2 = (lane + 128 < 147) ? lane + 128 : 146;
       float s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll 1
-      for (int blk = 0; blk < 4; blk++) {          // 240 = 3*64 + 48
-        const float av = x4[64 * blk + lane];
+      for (int j0 = 0; j0 < 240; j0 += 8) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(x4 + j0), a1 = *reinterpret_cast<const float4 *>(x4 + j0 + 4);
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float b0[8], b1[8], b2[8];
 #pragma unroll
-        for (int u0 = 0; u0 < 64; u0 += 8) {
-          if (64 * blk + u0 < 240) {
-            float b0[8], b1[8], b2[8];
+        for (int u = 0; u < 8; u++) { b0[u] = y4[i0 + j0 + u]; b1[u] = y4[i1 + j0 + u]; b2[u] = y4[i2 + j0 + u]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const int j = 64 * blk + u0 + u;
-              b0[u] = y4[i0 + j]; b1[u] = y4[i1 + j]; b2[u] = y4[i2 + j];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const float a = PN_BCAST(av, u0 + u);
-              s0 = s0 + a * b0[u]; s1 = s1 + a * b1[u]; s2 = s2 + a * b2[u];
-            }
-          }
-        }
+        for (int u = 0; u < 8; u++) { s0 = s0 + a[u] * b0[u]; s1 = s1 + a[u] * b1[u]; s2 = s2 + a[u] * b2[u]; }
       }
       xcorr[i0] = s0; xcorr[i1] = s1;
       if (lane + 128 < 147) xcorr[i2] = s2;
     }
     PN_WAVE_SYNC();
     int bp0, bp1;
-    pn_find_best_pitch<240, 147>(xcorr, y4, lane, bp0, bp1);
+    pn_find_best_pitch<240, 147>(xcorr, y4, sq64, x4, lane, bp0, bp1);   // x_lp4 is dead: its space holds d[]
     PN_WAVE_SYNC();
     // fine: only lags within +-2 of 2*best (pitch.cpp:344-361); other entries are 0
     for (int i = lane; i < 294; i += LANES) xcorr[i] = 0;
@@ -487,11 +499,11 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
     {
       const int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
       const bool act = lane < 10 && c >= 0 && c < 294;
-      const float sum = pn_chain_u<480>(pbuf + 384, pbuf + (act ? c : 0), 0.f, lane);
+      const float sum = pn_chain_u<480>(pbuf + 384, pbuf + (act ? c : 0), 0.f);
       if (act) xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
     }
     PN_WAVE_SYNC();
-    pn_find_best_pitch<480, 294>(xcorr, pbuf, lane, bp0, bp1);
+    pn_find_best_pitch<480, 294>(xcorr, pbuf, sq64, y4, lane, bp0, bp1);   // y_lp4 is dead: its space holds d[]
     int offset = 0;
     if (bp0 > 0 && bp0 < 294 - 1) {
       const float a = xcorr[bp0 - 1], b = xcorr[bp0], c = xcorr[bp0 + 1];
@@ -521,27 +533,35 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
         else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
         lag = (lane < 16) ? T1 : T1b;
       }
-      const float dot = pn_chain_u<480>(x, x - lag, 0.f, lane);   // lanes >= 30 shadow lag 0
+      const float dot = pn_chain_u<480>(x, x - lag, 0.f);   // lanes >= 30 shadow lag 0
       const float xx = __shfl(dot, 0);
       float xy = __shfl(dot, 1);
-      // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, wave-uniform; operands
-      // fetched 64 per block (one per lane) and broadcast, results collected one per lane
+      // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, wave-uniform.  The squares
+      // x[-i]^2 and x[N-i]^2 are formed lane-parallel, 64 at a time, into a broadcast scratch (the
+      // dead xcorr area); the recurrence then reads them 4 per ds_read_b128 and lane 0 stores the
+      // clamped results 4 at a time (yyl[1] is 16-byte aligned).
       {
+        float *pq = xcorr;                     // p[64] | q[64]
         float yy = xx;
         if (lane == 0) yyl[0] = xx;
 #pragma unroll 1
         for (int blk = 0; blk < 6; blk++) {        // i = 1 + 64*blk + u, u < 64  (384 = 6*64)
           const int i = 1 + 64 * blk + lane;
           const float a = x[-i], c = x[480 - i];
-          const float pv = a * a, qv = c * c;
-          float keep = 0;
+          PN_WAVE_SYNC();
+          pq[lane] = a * a; pq[64 + lane] = c * c;
+          PN_WAVE_SYNC();
 #pragma unroll
-          for (int u = 0; u < 64; u++) {
-            yy = yy + PN_BCAST(pv, u) - PN_BCAST(qv, u);
-            const float cl = (0 > yy) ? 0 : yy;
-            keep = (lane == u) ? cl : keep;
+          for (int v = 0; v < 16; v++) {
+            const float4 p4 = *reinterpret_cast<const float4 *>(pq + 4 * v);
+            const float4 q4 = *reinterpret_cast<const float4 *>(pq + 64 + 4 * v);
+            float4 o;
+            yy = yy + p4.x - q4.x; o.x = (0 > yy) ? 0 : yy;
+            yy = yy + p4.y - q4.y; o.y = (0 > yy) ? 0 : yy;
+            yy = yy + p4.z - q4.z; o.z = (0 > yy) ? 0 : yy;
+            yy = yy + p4.w - q4.w; o.w = (0 > yy) ? 0 : yy;
+            if (lane == 0) *reinterpret_cast<float4 *>(yyl + 1 + 64 * blk + 4 * v) = o;
           }
-          yyl[i] = keep;
         }
       }
       PN_WAVE_SYNC();
@@ -576,7 +596,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_fronten
       }
       best_xy = (0 > best_xy) ? 0 : best_xy;
       if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
-      const float xc = pn_chain_u<480>(x, x - (Tsel + (lane < 3 ? lane : 2) - 1), 0.f, lane);
+      const float xc = pn_chain_u<480>(x, x - (Tsel + (lane < 3 ? lane : 2) - 1), 0.f);
       const float xc0 = __shfl(xc, 0), xc1 = __shfl(xc, 1), xc2 = __shfl(xc, 2);
       int off2;
       if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
