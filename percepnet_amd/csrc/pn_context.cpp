@@ -12,9 +12,9 @@
 
 // ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
 struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
-void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int frame_t, const void *in, int in_is_i16,
-                        float *hist, float2 *Xs, float2 *Ps, float *feat, int *silence, int *last_period,
-                        float *last_gain, int blocks_per_cu);
+void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
+                        int in_is_i16, float *hist, float2 *yring, float *eyring, float2 *Ps, float *feat,
+                        int *silence, int *last_period, float *last_gain);
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
 size_t pn_packed_floats(int K, int ncols, int ct_round);
@@ -138,7 +138,7 @@ static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2",
 struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
 
 struct pn_ctx {
-  int device, B, nn_mode, fe_bpc;
+  int device, B, nn_mode;
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
   int64_t t;                       // frames done
@@ -147,7 +147,8 @@ struct pn_ctx {
   DevLayer L[PN_NLAYERS];
   PnTables *tables; float *tansig;
   float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
-  float2 *Xs, *Ps;
+  float2 *yring, *Ps;              // yring: [6][B][400] look-ahead spectra (X of frame t = slot (t+1)%6)
+  float *eyring;                   // [6][B][36] look-ahead band energies
   int *last_period, *silence;
   std::vector<void *> allocs;
   bool profiling;
@@ -176,6 +177,8 @@ static int zero_state(pn_ctx *c) {
   const size_t B = c->B;
   PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->synth, 0, B * PN_FRAME * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->yring, 0, 6 * B * PN_SPEC_BINS * sizeof(float2), c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->eyring, 0, 6 * B * 36 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->last_gain, 0, B * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->last_period, 0, B * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->silence, 0, B * 4, c->stream));
@@ -216,7 +219,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
-  c->fe_bpc = getenv("PN_FE_BPC") ? atoi(getenv("PN_FE_BPC")) : 0;   // tuning knob (front-end blocks per CU)
+
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { pn_set_error("hipStreamCreate failed"); delete c; return NULL; }
@@ -238,7 +241,8 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   DEV_ALLOC(c->last_gain, B, false);
   DEV_ALLOC(c->last_period, B, false);
   DEV_ALLOC(c->silence, B, false);
-  DEV_ALLOC(c->Xs, B * PN_SPEC_BINS, true);
+  DEV_ALLOC(c->yring, 6 * B * PN_SPEC_BINS, false);
+  DEV_ALLOC(c->eyring, 6 * B * 36, false);
   DEV_ALLOC(c->Ps, B * PN_SPEC_BINS, true);
   DEV_ALLOC(c->feat, Bp * PN_FEAT_STRIDE, false);
   DEV_ALLOC(c->c1ring, 5 * Bp * 128, false);
@@ -377,11 +381,13 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
   PN_HIP_CHECK(hipSetDevice(c->device));
   { Scope sc(c, KF_FRONTEND);
-    pn_launch_frontend(c->stream, c->tables, c->B, (int)(c->t % PN_HIST_FRAMES), d_in, is_i16, c->hist, c->Xs, c->Ps,
-                       c->feat, c->silence, c->last_period, c->last_gain, c->fe_bpc); }
+    pn_launch_frontend(c->stream, c->tables, c->B, c->t, d_in, is_i16, c->hist, c->yring, c->eyring, c->Ps,
+                       c->feat, c->silence, c->last_period, c->last_gain); }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
-    pn_launch_backend(c->stream, c->tables, c->B, c->Xs, c->Ps, c->gr, c->silence, c->synth, d_out, is_i16); }
+    // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6
+    const float2 *Xs = c->yring + (size_t)((c->t + 1) % 6) * c->B * PN_SPEC_BINS;
+    pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, c->silence, c->synth, d_out, is_i16); }
   if (d_gr) PN_HIP_CHECK(hipMemcpyAsync(d_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToDevice, c->stream));
   PN_HIP_CHECK(hipGetLastError());
   c->t++;

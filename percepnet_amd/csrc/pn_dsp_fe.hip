@@ -1,0 +1,775 @@
+// Front end of the PercepNet frame engine for gfx950: history ring write, window + 960-pt FFT
+// (look-ahead and comb-filtered frame), ERB band energies / correlation, CELT pitch analysis
+// (downsample + LPC whitening, coarse/fine xcorr search, octave-error removal), 7-tap comb filter,
+// 70 features == compute_frame_features + compute_lookahead_band_energy + create_features
+// (reference denoise.cpp:372-434, 498-506, 487-496).
+//
+// Mapping: FOUR streams per wavefront, 16 lanes each ("group").  The reference's per-frame work is
+// dominated by short, strictly sequential float chains (inner products per pitch lag, running
+// energies, Levinson, the best-pitch scan) that need 1..30 lanes; with one stream per wave most
+// of the 64 lanes execute redundant copies.  With 16 lanes per stream every wave instruction of
+// those phases advances four streams, and the data-parallel phases (FFT butterflies, windows,
+// comb filter) simply take 4x the iterations at 16 lanes each — same work per stream.
+//
+// Numerics contract (unchanged): every arithmetic step is the reference's operation in the
+// reference's order with separate IEEE binary32 rounding (-ffp-contract=off; divide/sqrt
+// correctly rounded; the reference's double islands in double).  Order-sensitive reductions run
+// as the reference's sequential chain on one lane (lane = lag / band); only the adds of a chain
+// are serially dependent, operands are fetched ahead.  Chain operands that are uniform within a
+// group (the x every lag is correlated against, the squares of the running-energy recurrences) are
+// read with one ds_read_b128 per 4 steps at a group-uniform address.  Features, silence flags,
+// pitch decisions are bit-identical to the CPU reference (tests/test_gpu_parity.py).
+//
+// One forward FFT per frame is saved exactly: the analysis window of frame t (comb_buf[2400,3360))
+// holds the same samples, window and transform as the look-ahead window of frame t-5
+// (comb_buf[4800,5760) then), so X(t) == Y(t-5) and Ex(t) == Ey(t-5) bit for bit; the look-ahead
+// spectra are kept in a 6-slot ring in HBM (slot t%6 written, slot (t+1)%6 = Y(t-5) read; the
+// back end reads that slot too).
+//
+// Work distribution: 256-thread blocks = 4 waves = 16 concurrent streams; the block stages the
+// shared tables (twiddles, window, digit reversal, band map: 13.6 KB) into LDS once; every
+// stream owns a private 8.3 KB LDS slice (FFT buffer, aliased by the pitch scratch); one block
+// per CU (146 KB LDS), grid-stride over stream quartets.  No block barrier after the staging:
+// groups never exchange data, LDS operations of one wave execute in order, PN_WAVE_SYNC is a
+// compiler fence.
+#include "pn_common.h"
+
+#define LANES 64
+#ifndef PN_FE_G
+#define PN_FE_G 4               // streams per wave (4 or 2)
+#endif
+#define G PN_FE_G
+#define L (LANES / G)           // lanes per stream
+#define FE_WPB (16 / G)         // waves per block: 16 streams per block (146 KB LDS, one block per CU)
+#define NCH ((147 + L - 1) / L) // coarse-search lags per lane
+#define NBND ((PN_NB + L - 1) / L)
+#define FE_THREADS (LANES * FE_WPB)
+#define FE_SPB (FE_WPB * G)     // streams per block
+
+#define PN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define PN_WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct alignas(16) FeTablesLds {
+  float2 tw[PN_NFFT];            // 7680 B
+  float win[PN_FRAME];           // 1920 B
+  float frac[PN_SPEC_BINS];      // 1600 B
+  int16_t bitrev[PN_NFFT];       // 1920 B
+  int16_t border[PN_NB + 2];
+  uint8_t band[PN_SPEC_BINS];
+  float comb_w[8];
+};
+struct alignas(16) FeStreamLds {
+  float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
+  float e[4][PN_NB + 2];         // 576 B
+};
+struct FeShared {
+  FeTablesLds t;
+  FeStreamLds s[FE_SPB];
+};
+
+// float offsets inside a stream's 1920-float buffer during the pitch section (see kernel)
+#define OFF_XCORR 0      // [0,296)    xcorr[294]; later p|q scratch of yy_lookup (128)
+#define OFF_Y4 304       // [304,691)  y_lp4[387]; later d[] of the fine pass (296)
+#define OFF_YYL 307      // [307,692)  yy_lookup[385]; &yyl[1] is 16-byte aligned
+#define OFF_SQ 704       // [704,768)  64-float broadcast scratch
+#define OFF_RAW 0        // [0,864)    decimated signal before the whitening FIR
+#define OFF_PBUF 864     // [864,1728) whitened decimated signal  (pitch_buf>>1)
+#define OFF_D1 1728      // [1728,1876) d[] of the coarse pass (148)
+#define OFF_PROD 960     // [960,1360) per-bin X.P products (after the P FFT; bins live in [0,800))
+
+#define CMUL(m, a, b) do { (m).x = (a).x*(b).x - (a).y*(b).y; (m).y = (a).x*(b).y + (a).y*(b).x; } while (0)
+
+// ---- 960-point FFT in LDS by L lanes (opus_fft_impl, kiss_fft.cpp:518-564, factors 5,3,4,4,4);
+// input already scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585) --------------------
+__device__ __forceinline__ void fe_fft960(float2 *F, const float2 *tw, int l) {
+  PN_WAVE_SYNC();
+#pragma unroll 5
+  for (int b = l; b < 240; b += L) {        // radix-4, m=1 (kiss_fft.cpp:112-131)
+    float2 *f = F + 4 * b;
+    float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
+    s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
+    f0.x += f2.x; f0.y += f2.y;
+    s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
+    f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
+    f0.x += s1.x; f0.y += s1.y;
+    s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
+    f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
+    f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
+    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
+  }
+  PN_WAVE_SYNC();
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {    // radix-4, m=4 (fstride 60) then m=16 (fstride 15) (139-166)
+    const int m = pass ? 16 : 4, fs = pass ? 15 : 60, mm = pass ? 64 : 16;
+#pragma unroll 5
+    for (int b = l; b < 240; b += L) {
+      const int i = b / m, j = b % m;
+      float2 *f = F + i * mm + j;
+      float2 f0 = f[0], fm = f[m], f2m = f[2 * m], f3m = f[3 * m];
+      const float2 t1 = tw[j * fs], t2 = tw[2 * j * fs], t3 = tw[3 * j * fs];
+      float2 s0, s1, s2, s3, s4, s5;
+      CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
+      s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
+      f0.x += s1.x; f0.y += s1.y;
+      s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
+      s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
+      f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
+      f0.x += s3.x; f0.y += s3.y;
+      fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
+      f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
+      f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
+    }
+    PN_WAVE_SYNC();
+  }
+  {
+    const float epi3 = tw[320].y;           // radix-3, m=64, fstride 5 (196-227)
+#pragma unroll 5
+    for (int b = l; b < 320; b += L) {
+      const int i = b >> 6, j = b & 63;
+      float2 *f = F + i * 192 + j;
+      float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
+      CMUL(s1, fm, tw[j * 5]); CMUL(s2, f2m, tw[2 * j * 5]);
+      s3.x = s1.x + s2.x; s3.y = s1.y + s2.y;
+      s0.x = s1.x - s2.x; s0.y = s1.y - s2.y;
+      fm.x = f0.x - s3.x * .5f; fm.y = f0.y - s3.y * .5f;
+      s0.x *= epi3; s0.y *= epi3;
+      f0.x += s3.x; f0.y += s3.y;
+      f2m.x = fm.x + s0.y; f2m.y = fm.y - s0.x;
+      fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
+      f[0] = f0; f[64] = fm; f[128] = f2m;
+    }
+    PN_WAVE_SYNC();
+  }
+  {
+    const float2 ya = tw[192], yb = tw[384]; // radix-5, m=192, fstride 1 (259-304)
+#pragma unroll 4
+    for (int u = l; u < 192; u += L) {
+      float2 *f = F + u;
+      float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
+      float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
+      CMUL(s1, f1, tw[u]); CMUL(s2, f2, tw[2 * u]); CMUL(s3, f3, tw[3 * u]); CMUL(s4, f4, tw[4 * u]);
+      s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
+      s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
+      s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
+      s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
+      f0.x = f0.x + (s7.x + s8.x);
+      f0.y = f0.y + (s7.y + s8.y);
+      s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
+      s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
+      s6.x = s10.y * ya.y + s9.y * yb.y;
+      s6.y = -(s10.x * ya.y + s9.x * yb.y);
+      f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
+      f4.x = s5.x + s6.x; f4.y = s5.y + s6.y;
+      s11.x = s0.x + (s7.x * yb.x + s8.x * ya.x);
+      s11.y = s0.y + (s7.y * yb.x + s8.y * ya.x);
+      s12.x = s9.y * ya.y - s10.y * yb.y;
+      s12.y = s10.x * yb.y - s9.x * ya.y;
+      f2.x = s11.x + s12.x; f2.y = s11.y + s12.y;
+      f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
+      f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
+    }
+    PN_WAVE_SYNC();
+  }
+}
+
+// ---- band reductions (denoise.cpp:89-160): the lane owning band b sums in the reference's order.
+// PROD=false: tmp = |A[k]|^2 (compute_band_energy); PROD=true: tmp[k] precomputed (compute_band_corr).
+template <bool PROD>
+__device__ __forceinline__ float fe_band(const FeTablesLds &T, const float2 *A, const float *prod, int b) {
+  float sum = 0;
+  if (b < PN_NB) {
+    if (b >= 1) {
+      const int lo = T.border[b - 1], hi = T.border[b];
+      for (int k = lo; k < hi; k++) {
+        float tmp;
+        if (PROD) tmp = prod[k];
+        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
+        sum += T.frac[k] * tmp;
+      }
+    }
+    if (b <= PN_NB - 2) {
+      const int lo = T.border[b], hi = T.border[b + 1];
+      for (int k = lo; k < hi; k++) {
+        float tmp;
+        if (PROD) tmp = prod[k];
+        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
+        sum += (1 - T.frac[k]) * tmp;
+      }
+    }
+    if (b == 0 || b == PN_NB - 1) sum *= 2;
+  }
+  return sum;
+}
+
+// logical comb_buf index j in [0,5760) (newest sample at 5759) -> ring offset
+__device__ __forceinline__ int fe_ring(int j, int base_slot) {
+  const int f = j / PN_FRAME;
+  int slot = base_slot + f;
+  if (slot >= PN_HIST_FRAMES) slot -= PN_HIST_FRAMES;
+  return slot * PN_FRAME + (j - f * PN_FRAME);
+}
+
+// acc + sum_{j<N} a[j]*b[j], adds strictly in j order (celt_inner_prod / xcorr_kernel, pitch.h:53-144).
+// `a` is uniform within the group: ds_read_b128 at one address (16-byte aligned); b is per lane.
+// Two register sets: the LDS reads of block k+1 are in flight while the (serially dependent) adds
+// of block k execute.
+#define FE_CH_LOAD(av, bv, blk) do {                                                                   \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
+    _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) (bv)[u_] = b[16 * (blk) + u_];                   \
+  } while (0)
+#define FE_CH_MAC(av, bv) do {                                                                         \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                                 \
+      acc = acc + (av)[v_].x * (bv)[4 * v_]; acc = acc + (av)[v_].y * (bv)[4 * v_ + 1];                \
+      acc = acc + (av)[v_].z * (bv)[4 * v_ + 2]; acc = acc + (av)[v_].w * (bv)[4 * v_ + 3];            \
+    }                                                                                                  \
+  } while (0)
+template <int N>
+__device__ __forceinline__ float fe_chain(const float *a, const float *b, float acc) {
+  constexpr int U = 16, NF = N / U, R = N % U;
+  float4 a0[4], a1[4]; float b0[U], b1[U];
+  FE_CH_LOAD(a0, b0, 0);
+#pragma unroll 1
+  for (int blk = 0; blk < NF; blk += 2) {
+    if (blk + 1 < NF) FE_CH_LOAD(a1, b1, blk + 1);
+    FE_CH_MAC(a0, b0);
+    if (blk + 2 < NF) FE_CH_LOAD(a0, b0, blk + 2);
+    if (blk + 1 < NF) FE_CH_MAC(a1, b1);
+  }
+  if (R) {
+    float4 av[R / 4 ? R / 4 : 1]; float bv[R ? R : 1];
+#pragma unroll
+    for (int v = 0; v < R / 4; v++) av[v] = *reinterpret_cast<const float4 *>(a + U * NF + 4 * v);
+#pragma unroll
+    for (int u = 0; u < R; u++) bv[u] = b[U * NF + u];
+#pragma unroll
+    for (int v = 0; v < R / 4; v++) {
+      acc = acc + av[v].x * bv[4 * v]; acc = acc + av[v].y * bv[4 * v + 1];
+      acc = acc + av[v].z * bv[4 * v + 2]; acc = acc + av[v].w * bv[4 * v + 3];
+    }
+  }
+  return acc;
+}
+#undef FE_CH_LOAD
+#undef FE_CH_MAC
+// two chains sharing the uniform operand: acc1 += a.b1, acc2 += a.b2
+#define FE_CH2_LOAD(av, v1, v2, blk) do {                                                              \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
+    _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) { (v1)[u_] = b1[16 * (blk) + u_]; (v2)[u_] = b2[16 * (blk) + u_]; } \
+  } while (0)
+#define FE_CH2_MAC(av, v1, v2) do {                                                                    \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                                 \
+      acc1 = acc1 + (av)[v_].x * (v1)[4 * v_]; acc2 = acc2 + (av)[v_].x * (v2)[4 * v_];                \
+      acc1 = acc1 + (av)[v_].y * (v1)[4 * v_ + 1]; acc2 = acc2 + (av)[v_].y * (v2)[4 * v_ + 1];        \
+      acc1 = acc1 + (av)[v_].z * (v1)[4 * v_ + 2]; acc2 = acc2 + (av)[v_].z * (v2)[4 * v_ + 2];        \
+      acc1 = acc1 + (av)[v_].w * (v1)[4 * v_ + 3]; acc2 = acc2 + (av)[v_].w * (v2)[4 * v_ + 3];        \
+    }                                                                                                  \
+  } while (0)
+template <int N>
+__device__ __forceinline__ void fe_chain2(const float *a, const float *b1, const float *b2, float &acc1, float &acc2) {
+  constexpr int U = 16, NF = N / U;
+  static_assert(N % U == 0 && NF % 2 == 0, "N");
+  float4 a0[4], a1[4]; float p0[U], q0[U], p1[U], q1[U];
+  FE_CH2_LOAD(a0, p0, q0, 0);
+#pragma unroll 1
+  for (int blk = 0; blk < NF; blk += 2) {
+    FE_CH2_LOAD(a1, p1, q1, blk + 1);
+    FE_CH2_MAC(a0, p0, q0);
+    if (blk + 2 < NF) FE_CH2_LOAD(a0, p0, q0, blk + 2);
+    FE_CH2_MAC(a1, p1, q1);
+  }
+}
+#undef FE_CH2_LOAD
+#undef FE_CH2_MAC
+
+// find_best_pitch (pitch.cpp:46-104, float instantiation).  Group-uniform recurrence on broadcast
+// operands: the squares y[j]^2 (64 at a time into sq) and the window updates
+// d[i] = y[i+LEN]^2 - y[i]^2 are formed lane-parallel first (same roundings), so the serial loops
+// are one add (resp. add + max + compare) per step.  xcorr, d, sq 16-byte aligned.
+template <int LEN, int MAXP>
+__device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const float *y, float *sq, float *d, int l,
+                                                   int &bp0, int &bp1) {
+  constexpr int MP4 = (MAXP + 3) & ~3;
+  for (int i = l; i < MP4; i += L) {
+    const int ic = i < MAXP ? i : MAXP - 1;
+    const float a = y[ic + LEN], c = y[ic];
+    d[i] = a * a - c * c;
+  }
+  float Syy = 1.0f;
+#pragma unroll 1
+  for (int blk = 0; blk < (LEN + 63) / 64; blk++) {
+    float yv[64 / L];
+#pragma unroll
+    for (int w = 0; w < 64 / L; w++) { const int j = 64 * blk + l + L * w; yv[w] = y[j < LEN ? j : 0]; }
+    PN_WAVE_SYNC();
+#pragma unroll
+    for (int w = 0; w < 64 / L; w++) sq[l + L * w] = yv[w] * yv[w];
+    PN_WAVE_SYNC();
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      if (64 * blk + 4 * v < LEN) {
+        const float4 q = *reinterpret_cast<const float4 *>(sq + 4 * v);
+        Syy = Syy + q.x; Syy = Syy + q.y; Syy = Syy + q.z; Syy = Syy + q.w;
+      }
+    }
+  }
+  PN_WAVE_SYNC();
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  bp0 = 0; bp1 = 1;
+#define FE_FBP_STEP(xc_, dd_, idx_)                                                                  \
+  if ((idx_) < MAXP) {                                                                              \
+    if ((xc_) > 0) {                                                                                \
+      float x16 = (xc_);                                                                            \
+      x16 *= 1e-12f;                                                                                \
+      const float num = x16 * x16;                                                                  \
+      if (num * bd1 > bn1 * Syy) {                                                                  \
+        if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = (idx_); } \
+        else { bn1 = num; bd1 = Syy; bp1 = (idx_); }                                                \
+      }                                                                                             \
+    }                                                                                               \
+    Syy += (dd_);                                                                                   \
+    Syy = (1 > Syy) ? 1 : Syy;                                                                      \
+  }
+#pragma unroll 1
+  for (int i0 = 0; i0 < MAXP; i0 += 16) {
+    float4 xv[4], dv[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = (i0 + 4 * v < MP4) ? i0 + 4 * v : 0;
+      xv[v] = *reinterpret_cast<const float4 *>(xcorr + i);
+      dv[v] = *reinterpret_cast<const float4 *>(d + i);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      FE_FBP_STEP(xv[v].x, dv[v].x, i0 + 4 * v) FE_FBP_STEP(xv[v].y, dv[v].y, i0 + 4 * v + 1)
+      FE_FBP_STEP(xv[v].z, dv[v].z, i0 + 4 * v + 2) FE_FBP_STEP(xv[v].w, dv[v].w, i0 + 4 * v + 3)
+    }
+  }
+#undef FE_FBP_STEP
+}
+
+__device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
+
+template <typename TIn>
+__global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
+    const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
+    const TIn *__restrict__ in,           // [n_streams][480]
+    float *__restrict__ hist,             // [n_streams][12][480] ring
+    float2 *__restrict__ yring,           // [6][n_streams][400] look-ahead spectra ring
+    float *__restrict__ eyring,           // [6][n_streams][36]  look-ahead band energies ring
+    float2 *__restrict__ Pspec,           // [n_streams][400]
+    float *__restrict__ feat,             // [n_streams][PN_FEAT_STRIDE]
+    int *__restrict__ silence,            // [n_streams]
+    int *__restrict__ last_period, float *__restrict__ last_gain) {
+  __shared__ FeShared SH;
+  const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid >> 6;
+  const int sub = lane / L, l = lane % L, gb = sub * L;
+  {
+    FeTablesLds &S = SH.t;
+    for (int i = tid; i < PN_NFFT; i += FE_THREADS) {
+      S.tw[i] = make_float2(T->tw[2 * i], T->tw[2 * i + 1]);
+      S.bitrev[i] = T->bitrev[i];
+    }
+    for (int i = tid; i < PN_FRAME; i += FE_THREADS) S.win[i] = T->half_window[i];
+    for (int i = tid; i < PN_SPEC_BINS; i += FE_THREADS) { S.frac[i] = T->bin_frac[i]; S.band[i] = T->bin_band[i]; }
+    if (tid < PN_NB + 2) S.border[tid] = T->border[tid];
+    if (tid < 8) S.comb_w[tid] = T->comb_hann[tid];
+    __syncthreads();
+  }
+  const FeTablesLds &S = SH.t;
+  FeStreamLds &W = SH.s[wave * G + sub];
+  float *buf = reinterpret_cast<float *>(W.fft);
+  float *pbuf = buf + OFF_PBUF, *xcorr = buf + OFF_XCORR, *y4 = buf + OFF_Y4, *yyl = buf + OFF_YYL,
+        *sq64 = buf + OFF_SQ, *d1 = buf + OFF_D1, *prod = buf + OFF_PROD, *raw = buf + OFF_RAW;
+  const int new_slot = frame_t % PN_HIST_FRAMES;
+  const int base_slot = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
+  const float scale = 1.f / PN_NFFT;
+
+  for (int s0 = (blockIdx.x * FE_WPB + wave) * G; s0 < n_streams; s0 += gridDim.x * FE_SPB) {
+    const int s = s0 + sub;
+    if (s < n_streams) {
+      float *h = hist + (size_t)s * PN_HIST;
+      // -- history: the shift+append of denoise.cpp:388-389 becomes one ring-slot write ---------
+#pragma unroll
+      for (int i4 = l; i4 < PN_FRAME / 4; i4 += L) {
+        float4 v;
+        if (sizeof(TIn) == 2) {
+          const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * PN_FRAME + 4 * i4);
+          v = make_float4(((float)q.x) / 32768.f, ((float)q.y) / 32768.f, ((float)q.z) / 32768.f, ((float)q.w) / 32768.f);  // main.cpp:34
+        } else {
+          v = *reinterpret_cast<const float4 *>(in + (size_t)s * PN_FRAME + 4 * i4);
+        }
+        *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = v;
+      }
+      PN_WAVE_SYNC_GLOBAL();
+      // -- Y = FFT(window(newest 960 samples)), Ey (compute_lookahead_band_energy 498-506); kept in
+      //    the ring: it is X / Ex of frame t+5 (frame_analysis 333-346) --------------------------------
+      {
+        constexpr int NI = (PN_WINDOW / 4 + L - 1) / L;   // float4 per lane (15 at L=16)
+        float4 hv[NI];
+#pragma unroll
+        for (int it = 0; it < NI; it++) {              // all global loads in flight before first use
+          const int i4 = l + L * it;
+          hv[it] = *reinterpret_cast<const float4 *>(h + fe_ring(PN_HIST - PN_WINDOW + 4 * (i4 < PN_WINDOW / 4 ? i4 : 0), base_slot));
+        }
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+          const int i = 4 * (l + L * it);
+          if (i >= PN_WINDOW) continue;
+          const float vv[4] = {hv[it].x, hv[it].y, hv[it].z, hv[it].w};
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int ii = i + c;
+            const float w = S.win[ii < PN_FRAME ? ii : PN_WINDOW - 1 - ii];   // apply_window 282-289
+            W.fft[S.bitrev[ii]] = make_float2(scale * (vv[c] * w), scale * 0.f);
+          }
+        }
+      }
+      fe_fft960(W.fft, S.tw, l);
+      {
+        float2 *yw = yring + ((size_t)slot_w * n_streams + s) * PN_SPEC_BINS;
+        for (int k = l; k < PN_SPEC_BINS; k += L) yw[k] = W.fft[k];
+        float *ew = eyring + ((size_t)slot_w * n_streams + s) * 36;
+#pragma unroll
+        for (int c = 0; c < NBND; c++) {
+          const int b = l + L * c;
+          const float e = fe_band<false>(S, W.fft, nullptr, b);
+          if (b < PN_NB) { ew[b] = e; W.e[1][b] = e; }          // Ey of this frame (features)
+        }
+      }
+      const float2 *Xr = yring + ((size_t)slot_r * n_streams + s) * PN_SPEC_BINS;   // X(t)  = Y(t-5)
+      const float *Exr = eyring + ((size_t)slot_r * n_streams + s) * 36;            // Ex(t) = Ey(t-5)
+      for (int b = l; b < PN_NB; b += L) W.e[0][b] = Exr[b];
+      PN_WAVE_SYNC();
+
+      // -- pitch_downsample (pitch.cpp:148-216) of pitch_buf == comb_buf[1632,3360) ----------------
+      // outputs 2m, 2m+1 need x[4m-1 .. 4m+3]
+      {
+        constexpr int NM = (432 + L - 1) / L;
+        float4 dv[NM]; float dm1[NM];
+#pragma unroll
+        for (int it = 0; it < NM; it++) {
+          const int m = (l + L * it < 432) ? l + L * it : 0;
+          dv[it] = *reinterpret_cast<const float4 *>(h + fe_ring(1632 + 4 * m, base_slot));
+          dm1[it] = h[fe_ring(1632 + (m > 0 ? 4 * m - 1 : 0), base_slot)];
+        }
+#pragma unroll
+        for (int it = 0; it < NM; it++) {
+          const int m = l + L * it;
+          if (m >= 432) continue;
+          const float4 v = dv[it];
+          const float o0 = (m == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (dm1[it] + v.y) + v.x);
+          const float o1 = .5f * (.5f * (v.y + v.w) + v.z);
+          *reinterpret_cast<float2 *>(raw + 2 * m) = make_float2(o0, o1);
+        }
+      }
+      PN_WAVE_SYNC();
+      // _celt_autocorr (celt_lpc.cpp:198-279): lane k holds lag k (lanes > 4 shadow lag 4)
+      float ac[5];
+      {
+        const int lag = l < 4 ? l : 4;
+        float ack = fe_chain<860>(raw, raw + lag, 0.f);
+        float d = 0;
+        for (int i = lag + 860; i < 864; i++) d = d + raw[i] * raw[i - lag];
+        ack += d;
+#pragma unroll
+        for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, gb + k);
+      }
+      ac[0] *= 1.0001f;
+#pragma unroll
+      for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+      // _celt_lpc (celt_lpc.cpp:37-88), p = 4; group-uniform
+      float lpc[4] = {0, 0, 0, 0};
+      {
+        float error = ac[0];
+        if (ac[0] != 0) {
+          bool done = false;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if (!done) {
+              float rr = 0;
+#pragma unroll
+              for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+              rr += ac[i + 1];
+              const float r = (float)((double)(-rr) / ((double)error + 0.00001));
+              lpc[i] = r;
+#pragma unroll
+              for (int j = 0; j < ((i + 1) >> 1); j++) {
+                const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+                lpc[j] = t1 + r * t2;
+                lpc[i - 1 - j] = t2 + r * t1;
+              }
+              error = error - (r * r) * error;
+              if (error < .001f * ac[0]) done = true;
+            }
+          }
+        }
+      }
+      float lpc2[5];
+      {
+        float tmp = 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { tmp = .9f * tmp; lpc[i] = lpc[i] * tmp; }
+        lpc2[0] = lpc[0] + .8f;
+        lpc2[1] = lpc[1] + .8f * lpc[0];
+        lpc2[2] = lpc[2] + .8f * lpc[1];
+        lpc2[3] = lpc[3] + .8f * lpc[2];
+        lpc2[4] = .8f * lpc[3];
+      }
+      // celt_fir5 (pitch.cpp:106-145): out of place, raw -> pbuf
+#pragma unroll 2
+      for (int i = l; i < 864; i += L) {
+        float sum = raw[i];
+        sum = sum + lpc2[0] * (i >= 1 ? raw[i - 1] : 0.f);
+        sum = sum + lpc2[1] * (i >= 2 ? raw[i - 2] : 0.f);
+        sum = sum + lpc2[2] * (i >= 3 ? raw[i - 3] : 0.f);
+        sum = sum + lpc2[3] * (i >= 4 ? raw[i - 4] : 0.f);
+        sum = sum + lpc2[4] * (i >= 5 ? raw[i - 5] : 0.f);
+        pbuf[i] = sum;
+      }
+      PN_WAVE_SYNC();
+
+      // -- pitch_search (pitch.cpp:283-386): x_lp = pbuf+384, y = pbuf, len 960, max_pitch 588 ----
+      // coarse: x_lp4[j] = pbuf[384+2j] (240, group-uniform operand, read straight from pbuf),
+      // y_lp4[j] = pbuf[2j] (387, copied out contiguously); lane owns lags l + L*c, c < NCH
+      for (int j = l; j < 387; j += L) y4[j] = pbuf[2 * j];
+      PN_WAVE_SYNC();
+      {
+        float sacc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sacc[c] = 0;
+        const int lmax = 146;
+#pragma unroll 1
+        for (int j0 = 0; j0 < 240; j0 += 4) {
+          const float4 a01 = *reinterpret_cast<const float4 *>(pbuf + 384 + 2 * j0);
+          const float4 a23 = *reinterpret_cast<const float4 *>(pbuf + 384 + 2 * j0 + 4);
+          const float a[4] = {a01.x, a01.z, a23.x, a23.z};
+          float bv[NCH][4];
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const int lag = (l + L * c <= lmax) ? l + L * c : lmax;
+#pragma unroll
+            for (int u = 0; u < 4; u++) bv[c][u] = y4[lag + j0 + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sacc[c] = sacc[c] + a[u] * bv[c][u];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) if (l + L * c < 147) xcorr[l + L * c] = sacc[c];
+      }
+      PN_WAVE_SYNC();
+      int bp0, bp1;
+      fe_find_best_pitch<240, 147>(xcorr, y4, sq64, d1, l, bp0, bp1);
+      PN_WAVE_SYNC();
+      // fine: only lags within +-2 of 2*best (pitch.cpp:344-361); other entries are 0
+      for (int i = l; i < 296; i += L) xcorr[i] = 0;
+      PN_WAVE_SYNC();
+      {
+        const int c = (l < 5) ? (2 * bp0 - 2 + l) : (2 * bp1 - 2 + (l - 5));
+        const bool act = l < 10 && c >= 0 && c < 294;
+        const float sum = fe_chain<480>(pbuf + 384, pbuf + (act ? c : 0), 0.f);
+        if (act) xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
+      }
+      PN_WAVE_SYNC();
+      fe_find_best_pitch<480, 294>(xcorr, pbuf, sq64, y4, l, bp0, bp1);   // y_lp4 is dead: its space holds d[]
+      int offset = 0;
+      if (bp0 > 0 && bp0 < 294 - 1) {
+        const float a = xcorr[bp0 - 1], b = xcorr[bp0], c = xcorr[bp0 + 1];
+        if ((c - a) > .7f * (b - a)) offset = 1;
+        else if ((a - c) > .7f * (b - c)) offset = -1;
+      }
+      const float pitch_corr = xcorr[bp0];
+      int pitch_index = PN_PITCH_MAX - (2 * bp0 - offset);       // denoise.cpp:408
+      PN_WAVE_SYNC();
+
+      // -- remove_doubling (pitch.cpp:424-527): maxperiod 384, minperiod 30, N 480, x = pbuf+384 -----
+      float pg;
+      {
+        const float *x = pbuf + 384;
+        const int prev_period = last_period[s] / 2;
+        const float prev_gain = last_gain[s];
+        int T0 = pitch_index / 2;
+        if (T0 >= 384) T0 = 383;
+        // lane 0: xx ; lane 1: xy(T0) ; lanes 2..15: k = l: xy(T1_k) and xy2(T1b_k)
+        int lag1 = 0, lag2 = 0, T1 = 0, T1b = 0;
+        const int k = l;
+        if (l == 1) { lag1 = T0; lag2 = T0; }
+        else if (l >= 2 && l < 16) {
+          static const int second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+          T1 = (2 * T0 + k) / (2 * k);
+          if (k == 2) { if (T1 + T0 > 384) T1b = T0; else T1b = T0 + T1; }
+          else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
+          lag1 = T1; lag2 = T1b;
+        }
+        float dot1 = 0, dot2 = 0;
+        fe_chain2<480>(x, x - lag1, x - lag2, dot1, dot2);
+        const float xx = __shfl(dot1, gb);
+        float xy = __shfl(dot1, gb + 1);
+        // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, group-uniform.  Squares
+        // formed lane-parallel, 64 at a time, into a broadcast scratch (the dead xcorr area); the
+        // recurrence reads them 4 per ds_read_b128; lane 0 stores the clamped results 4 at a time.
+        {
+          float *pq = xcorr;                     // p[64] | q[64]
+          float yy = xx;
+          if (l == 0) yyl[0] = xx;
+#pragma unroll 1
+          for (int blk = 0; blk < 6; blk++) {        // i = 1 + 64*blk + u, u < 64  (384 = 6*64)
+            float pa[64 / L], qa[64 / L];
+#pragma unroll
+            for (int w = 0; w < 64 / L; w++) {
+              const int i = 1 + 64 * blk + l + L * w;
+              const float a = x[-i], c = x[480 - i];
+              pa[w] = a * a; qa[w] = c * c;
+            }
+            PN_WAVE_SYNC();
+#pragma unroll
+            for (int w = 0; w < 64 / L; w++) { pq[l + L * w] = pa[w]; pq[64 + l + L * w] = qa[w]; }
+            PN_WAVE_SYNC();
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+              const float4 p4 = *reinterpret_cast<const float4 *>(pq + 4 * v);
+              const float4 q4 = *reinterpret_cast<const float4 *>(pq + 64 + 4 * v);
+              float4 o;
+              yy = yy + p4.x - q4.x; o.x = (0 > yy) ? 0 : yy;
+              yy = yy + p4.y - q4.y; o.y = (0 > yy) ? 0 : yy;
+              yy = yy + p4.z - q4.z; o.z = (0 > yy) ? 0 : yy;
+              yy = yy + p4.w - q4.w; o.w = (0 > yy) ? 0 : yy;
+              if (l == 0) *reinterpret_cast<float4 *>(yyl + 1 + 64 * blk + 4 * v) = o;
+            }
+          }
+        }
+        PN_WAVE_SYNC();
+        float yy = yyl[T0];
+        float best_xy = xy, best_yy = yy;
+        const float g0 = fe_pitch_gain(xy, xx, yy);
+        float g = g0;
+        int Tsel = T0;
+        // k = 2..15 evaluated in parallel on lanes 2..15 of the group; the sequential loop's "last hit
+        // wins" becomes "highest k among hits"; its `break` at T1 < minperiod is a prefix condition.
+        bool hit = false;
+        float xyk = 0, yyk = 0, g1 = 0;
+        if (l >= 2 && l < 16 && T1 >= 30) {
+          xyk = .5f * (dot1 + dot2);
+          yyk = .5f * (yyl[T1] + yyl[T1b]);
+          g1 = fe_pitch_gain(xyk, xx, yyk);
+          float cont;
+          const int dT = (T1 - prev_period) < 0 ? -(T1 - prev_period) : (T1 - prev_period);
+          if (dT <= 1) cont = prev_gain;
+          else if (dT <= 2 && 5 * k * k < T0) cont = .5f * prev_gain;
+          else cont = 0;
+          float thresh = (.3f > .7f * g0 - cont) ? .3f : .7f * g0 - cont;
+          if (T1 < 3 * 30) thresh = (.4f > .85f * g0 - cont) ? .4f : .85f * g0 - cont;
+          hit = g1 > thresh;
+        }
+        const unsigned m = (unsigned)((__ballot(hit) >> gb) & 0xffffull);   // hits live on lanes 2..15 of the group
+        if (m) {
+          const int win = gb + 31 - __clz(m);
+          best_xy = __shfl(xyk, win); best_yy = __shfl(yyk, win);
+          Tsel = __shfl(T1, win); g = __shfl(g1, win);
+        }
+        best_xy = (0 > best_xy) ? 0 : best_xy;
+        if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
+        const float xc = fe_chain<480>(x, x - (Tsel + (l < 3 ? l : 2) - 1), 0.f);
+        const float xc0 = __shfl(xc, gb), xc1 = __shfl(xc, gb + 1), xc2 = __shfl(xc, gb + 2);
+        int off2;
+        if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
+        else if ((xc0 - xc2) > .7f * (xc1 - xc2)) off2 = -1;
+        else off2 = 0;
+        if (pg > g) pg = g;
+        pitch_index = 2 * Tsel + off2;
+        if (pitch_index < PN_PITCH_MIN) pitch_index = PN_PITCH_MIN;
+      }
+      if (l == 0) { last_period[s] = pitch_index; last_gain[s] = pg; }
+      PN_WAVE_SYNC();
+
+      // -- comb filter (denoise.cpp:416-422) + window + FFT -> P, Ep, Exp -------------------------
+      {
+        constexpr int CH = (L == 16) ? 12 : 10;         // samples per lane per chunk: 84 / 70 loads in flight
+        static_assert((PN_WINDOW / L) % CH == 0, "chunk");
+#pragma unroll 1
+        for (int i0 = l; i0 < PN_WINDOW; i0 += L * CH) {
+          float cv[CH][7];
+#pragma unroll
+          for (int q = 0; q < CH; q++)
+#pragma unroll
+            for (int k = -PN_COMB_M; k <= PN_COMB_M; k++)
+              cv[q][k + PN_COMB_M] = h[fe_ring(2400 - pitch_index * k + i0 + L * q, base_slot)];
+#pragma unroll
+          for (int q = 0; q < CH; q++) {
+            const int i = i0 + L * q;
+            float p = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) p += cv[q][k] * S.comb_w[k];
+            const float v = p * S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
+            W.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+          }
+        }
+      }
+      fe_fft960(W.fft, S.tw, l);
+      {
+        constexpr int NK = PN_SPEC_BINS / L;            // 25 at L=16
+        float2 xv[NK];
+#pragma unroll
+        for (int it = 0; it < NK; it++) xv[it] = Xr[l + L * it];
+#pragma unroll
+        for (int it = 0; it < NK; it++) {
+          const int k = l + L * it;
+          const float2 P = W.fft[k];
+          Pspec[(size_t)s * PN_SPEC_BINS + k] = P;
+          float tmp = xv[it].x * P.x;            // compute_band_corr's per-bin term (denoise.cpp:136-137)
+          tmp += xv[it].y * P.y;
+          prod[k] = tmp;
+        }
+        for (int k = l + L * NK; k < PN_SPEC_BINS; k += L) {   // remainder when L does not divide 400
+          const float2 P = W.fft[k]; const float2 X = Xr[k];
+          Pspec[(size_t)s * PN_SPEC_BINS + k] = P;
+          float tmp = X.x * P.x; tmp += X.y * P.y; prod[k] = tmp;
+        }
+      }
+      float Ep[NBND];
+#pragma unroll
+      for (int c = 0; c < NBND; c++) Ep[c] = fe_band<false>(S, W.fft, nullptr, l + L * c);
+      PN_WAVE_SYNC();
+      float *f = feat + (size_t)s * PN_FEAT_STRIDE;
+#pragma unroll
+      for (int c = 0; c < NBND; c++) {
+        const int b = l + L * c;
+        float Exp = fe_band<true>(S, nullptr, prod, b);
+        if (b < PN_NB) {
+          const float Ex = W.e[0][b];
+          // double island, denoise.cpp:427
+          Exp = (float)fmin(1.0, fmax(0.0, (double)Exp / sqrt(1e-15 + (double)(Ex * Ep[c]))));
+          f[b] = W.e[1][b] * 30;              // create_features (487-496)
+          f[PN_NB + b] = Exp * 30;
+        }
+      }
+      // silence = sum(Ex) < 0.1 (429-433): sequential sum
+      if (l == 0) {
+        float E = 0;
+        for (int i = 0; i < PN_NB; i++) E += W.e[0][i];
+        silence[s] = ((double)E < 0.1) ? 1 : 0;
+        f[68] = (float)pitch_index / (PN_PITCH_MAX - 3 * PN_PITCH_MIN);
+        f[69] = pitch_corr;
+      }
+      PN_WAVE_SYNC();
+    }
+  }
+}
+
+// ---- launcher ---------------------------------------------------------------------------------
+void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
+                        int in_is_i16, float *hist, float2 *yring, float *eyring, float2 *Ps, float *feat,
+                        int *silence, int *last_period, float *last_gain) {
+  const int need = (n_streams + FE_SPB - 1) / FE_SPB;
+  const int grid = need < 256 ? need : 256;            // one 146 KB block per CU, grid-stride
+  const int frame_t = (int)(frame % PN_HIST_FRAMES);
+  const int slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
+  if (in_is_i16)
+    hipLaunchKernelGGL(pn_frontend_kernel<int16_t>, dim3(grid), dim3(FE_THREADS), 0, st, T, n_streams, frame_t,
+                       slot_w, slot_r, (const int16_t *)in, hist, yring, eyring, Ps, feat, silence, last_period,
+                       last_gain);
+  else
+    hipLaunchKernelGGL(pn_frontend_kernel<float>, dim3(grid), dim3(FE_THREADS), 0, st, T, n_streams, frame_t, slot_w,
+                       slot_r, (const float *)in, hist, yring, eyring, Ps, feat, silence, last_period, last_gain);
+}
