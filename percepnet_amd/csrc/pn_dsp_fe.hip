@@ -177,27 +177,30 @@ __device__ __forceinline__ void fe_fft960(float2 *F, const float2 *tw, int l) {
 template <bool PROD>
 __device__ __forceinline__ float fe_band(const FeTablesLds &T, const float2 *A, const float *prod, int b) {
   float sum = 0;
-  if (b < PN_NB) {
-    if (b >= 1) {
-      const int lo = T.border[b - 1], hi = T.border[b];
-      for (int k = lo; k < hi; k++) {
-        float tmp;
-        if (PROD) tmp = prod[k];
-        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
-        sum += T.frac[k] * tmp;
+  const bool valid = b < PN_NB;
+  const int bb = valid ? b : 0;
+  // interval i = b-1 contributes `sum[i+1] += frac*tmp`, interval i = b `sum[i] += (1-frac)*tmp`,
+  // each j ascending (denoise.cpp:97-104).  Operands are fetched 8 bins ahead of the add chain.
+#pragma unroll
+  for (int part = 0; part < 2; part++) {
+    const bool on = valid && (part == 0 ? bb >= 1 : bb <= PN_NB - 2);
+    const int lo = on ? T.border[part == 0 ? bb - 1 : bb] : 0;
+    const int hi = on ? T.border[part == 0 ? bb : bb + 1] : 0;
+    for (int k0 = lo; k0 < hi; k0 += 8) {
+      float tv[8], fv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = (k0 + u < hi) ? k0 + u : hi - 1;
+        if (PROD) tv[u] = prod[k];
+        else { const float2 a = A[k]; float t = a.x * a.x; t += a.y * a.y; tv[u] = t; }
+        fv[u] = T.frac[k];
       }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k0 + u < hi) sum += (part == 0 ? fv[u] : (1 - fv[u])) * tv[u];
     }
-    if (b <= PN_NB - 2) {
-      const int lo = T.border[b], hi = T.border[b + 1];
-      for (int k = lo; k < hi; k++) {
-        float tmp;
-        if (PROD) tmp = prod[k];
-        else { tmp = A[k].x * A[k].x; tmp += A[k].y * A[k].y; }
-        sum += (1 - T.frac[k]) * tmp;
-      }
-    }
-    if (b == 0 || b == PN_NB - 1) sum *= 2;
   }
+  if (valid && (b == 0 || b == PN_NB - 1)) sum *= 2;
   return sum;
 }
 
