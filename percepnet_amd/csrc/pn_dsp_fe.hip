@@ -444,6 +444,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       for (int b = l; b < PN_NB; b += L) W.e[0][b] = Exr[b];
       PN_WAVE_SYNC();
 
+#if defined(PN_FE_ABL) && PN_FE_ABL == 1
+      continue;   // timing ablation (tools/kernel_times.py): history write + look-ahead FFT + band energies only
+#endif
       // -- pitch_downsample (pitch.cpp:148-216) of pitch_buf == comb_buf[1632,3360) ----------------
       // outputs 2m, 2m+1 need x[4m-1 .. 4m+3]
       {
@@ -531,6 +534,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       }
       PN_WAVE_SYNC();
 
+#if defined(PN_FE_ABL) && PN_FE_ABL == 2
+      continue;   // timing ablation: + downsample, autocorr, LPC, FIR
+#endif
       // -- pitch_search (pitch.cpp:283-386): x_lp = pbuf+384, y = pbuf, len 960, max_pitch 588 ----
       // coarse: x_lp4[j] = pbuf[384+2j] (240, group-uniform operand, read straight from pbuf),
       // y_lp4[j] = pbuf[2j] (387, copied out contiguously); lane owns lags l + L*c, c < NCH
@@ -586,6 +592,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       int pitch_index = PN_PITCH_MAX - (2 * bp0 - offset);       // denoise.cpp:408
       PN_WAVE_SYNC();
 
+#if defined(PN_FE_ABL) && PN_FE_ABL == 3
+      continue;   // timing ablation: + pitch_search
+#endif
       // -- remove_doubling (pitch.cpp:424-527): maxperiod 384, minperiod 30, N 480, x = pbuf+384 -----
       float pg;
       {
@@ -686,6 +695,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       if (l == 0) { last_period[s] = pitch_index; last_gain[s] = pg; }
       PN_WAVE_SYNC();
 
+#if defined(PN_FE_ABL) && PN_FE_ABL == 4
+      continue;   // timing ablation: + remove_doubling
+#endif
       // -- comb filter (denoise.cpp:416-422) + window + FFT -> P, Ep, Exp -------------------------
       {
         constexpr int CH = (L == 16) ? 12 : 10;         // samples per lane per chunk: 84 / 70 loads in flight
