@@ -17,7 +17,7 @@ def aggregate_throughput(dist, my_stream_frames, my_seconds):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return my_stream_frames / my_seconds, my_seconds
     import torch
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"   # gloo reduces host tensors
     t = torch.tensor([my_seconds], dtype=torch.float64, device=dev)
     n = torch.tensor([float(my_stream_frames)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

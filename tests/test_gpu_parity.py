@@ -254,3 +254,53 @@ def test_rnnoise_drop_in_symbols(blob, oracle, tmp_path):
     assert np.abs(got.astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
     tapdata = np.fromfile(tap, np.float32).reshape(10, 68)
     assert np.abs(tapdata - rg).max() <= GR_TOL
+
+
+def test_cli_percepnet_run_matches_reference_cli_contract(blob, oracle, tmp_path):
+    """percepnet_run (csrc/percepnet_run.cpp) = the reference's `percepNet_run in.pcm out.pcm`
+    (main.cpp:11-44): raw int16 in, (frames-1)*480 samples out, ./feature_test.raw with 68 floats per
+    frame for a single pair; N pairs = N concurrent streams of different lengths."""
+    import subprocess
+    from percepnet_amd import build
+    exe = build.RUN
+    assert os.path.exists(exe), "percepnet_run not built"
+    (tmp_path / "m.pnw").write_bytes(blob)
+    a = synth.synth_stream(3, 20); b = synth.synth_stream(5, 13)
+    b_tail = np.concatenate([b, np.zeros(100, np.int16)])          # partial tail frame must be dropped
+    (tmp_path / "a.pcm").write_bytes(a.tobytes()); (tmp_path / "b.pcm").write_bytes(b_tail.tobytes())
+    r = subprocess.run([exe, "--model", "m.pnw", "a.pcm", "ao.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ao = np.fromfile(tmp_path / "ao.pcm", np.int16); tap = np.fromfile(tmp_path / "feature_test.raw", np.float32).reshape(-1, 68)
+    ro, rg = oracle.run_pcm(a)
+    assert ao.size == 19 * 480 and np.abs(ao.astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+    assert tap.shape == (20, 68) and np.abs(tap - rg).max() <= GR_TOL
+    r = subprocess.run([exe, "--model", "m.pnw", "--strict", "a.pcm", "ao2.pcm", "b.pcm", "bo2.pcm"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ao2 = np.fromfile(tmp_path / "ao2.pcm", np.int16); bo2 = np.fromfile(tmp_path / "bo2.pcm", np.int16)
+    rb, _ = oracle.run_pcm(b)
+    assert np.array_equal(ao2, ro) and np.array_equal(bo2, rb)      # strict mode: bit-exact, ragged lengths
+    r = subprocess.run([exe, "a.pcm"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+
+
+def test_multi_frame_device_api(model, oracle):
+    """pn_process_i16_multi: n_frames frame-major [T][B][480] in one call == T single calls."""
+    import torch
+    B, T = 5, 6
+    pcm = synth.synth_batch(B, T, first_stream=20)
+    fm = np.ascontiguousarray(pcm.reshape(B, T, 480).transpose(1, 0, 2))          # [T][B][480]
+    dev = torch.device("cuda:0")
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    d_in = torch.from_numpy(fm).to(dev); d_out = torch.empty_like(d_in)
+    d_gr = torch.empty((T, B, 68), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    rc = ctx.L.pn_process_i16_multi(ctx.h, d_in.data_ptr(), d_out.data_ptr(), d_gr.data_ptr(), T)
+    assert rc == 0
+    ctx.synchronize()
+    out = d_out.cpu().numpy(); gr = d_gr.cpu().numpy()
+    ro, rg = _oracle_batch(oracle, pcm)
+    for s in range(B):
+        assert np.array_equal(out[1:, s].reshape(-1), ro[s])
+        assert np.array_equal(gr[:, s], rg[s])
+    ctx.close()
