@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
+    ap.add_argument("--fp16", action="store_true",
+                    help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: <=3 LSB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
@@ -155,7 +157,7 @@ def main():
     blob = weights.default_blob(1234)
     model = api.Model(blob)
     stream = torch.cuda.current_stream()
-    ctx = api.Context(model, B, device=local_rank, nn_mode=api.NN_STRICT if a.strict else api.NN_MFMA,
+    ctx = api.Context(model, B, device=local_rank, nn_mode=api.NN_STRICT if a.strict else (api.NN_MFMA_F16 if a.fp16 else api.NN_MFMA),
                       stream=stream.cuda_stream)
 
     # synthetic input, resident in HBM: a pool of 64 distinct streams (voiced / bursts+silence /
@@ -209,12 +211,15 @@ def main():
             "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "max_abs_delta_vs_cpu_ref_lsb": "<=1 (tests/test_gpu_parity.py; STRICT mode 0)",
+            "dtype": "f16 GEMM operands, f32 accumulate/state/DSP" if a.fp16 else "f32", "data": "synthetic",
+            "max_abs_delta_vs_cpu_ref_lsb": ("<=3 (fp16 variant, tests/test_gpu_parity.py::test_fp16_variant_tolerance)" if a.fp16
+                                             else "<=1 (tests/test_gpu_parity.py; STRICT mode 0)"),
             "config": {
                 "workload": ("configs[2]: 65536 concurrent 48 kHz streams per MI355X, fp32 network as MFMA GEMM"
-                             if B == 65536 else f"{B} concurrent 48 kHz streams per MI355X (configs[1] = 1024)"),
-                "streams_per_gpu": B, "frame_samples": FRAME, "nn_mode": "strict" if a.strict else "mfma_f32",
+                             if (B == 65536 and not a.fp16) else
+                             ("configs[4]: fp16 weights/activations variant, " if a.fp16 else "") +
+                             f"{B} concurrent 48 kHz streams per MI355X (configs[1] = 1024)"),
+                "streams_per_gpu": B, "frame_samples": FRAME, "nn_mode": "strict" if a.strict else ("mfma_f16" if a.fp16 else "mfma_f32"),
                 "weights": "torch.manual_seed(1234) default-init PercepNet in nnet_data.h layout",
                 "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective",
                 "io": "int16 PCM resident in HBM",
@@ -231,15 +236,16 @@ def main():
                 flops = B * GRU512_FLOP_PER_STREAM_FRAME
                 traffic, traffic_src = pmc_traffic_bytes(B)
                 ach = flops / avg_s / 1e12
+                peak = 2500.0 if a.fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
                 res["roofline"] = {
-                    "kernel": "pn_gru_mfma_kernel (512->512 reset-after GRU step, 4 launches per frame)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else "pn_gru_mfma_kernel") + " (512->512 reset-after GRU step, 4 launches per frame)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None if a.fp16 else traffic,
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": 3 * B * 512 * 4 + 2 * 512 * 1536 * 4,   # x, h read; h' written; W,U once
                     "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4),
                     "whole_pipeline_tflops": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2),
-                    "whole_pipeline_frac_of_mfma_peak": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "whole_pipeline_frac_of_mfma_peak": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / peak, 4),
                     "algorithmic_hbm_gbs": round(fps / n_gpus * (62608 + 31850256 / B) / 1e9, 1),
                 }
         if cpu is not None:

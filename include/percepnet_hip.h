@@ -42,8 +42,11 @@ enum {
   PN_NN_MFMA = 0,    /* fp32 MFMA GEMM over the stream batch (v_mfma_f32_32x32x2_f32): each output
                         is a k-ascending fmaf chain from the bias — the reference's summation
                         order (nnet.cpp:59-72) with fused instead of separate rounding */
-  PN_NN_STRICT = 1   /* one lane per (stream, neuron), separate mul and add in the reference's
+  PN_NN_STRICT = 1,  /* one lane per (stream, neuron), separate mul and add in the reference's
                         order: bit-identical to the CPU reference; slow, for parity tests */
+  PN_NN_MFMA_F16 = 2 /* BASELINE configs[4]: GEMM operands (weights and activations) rounded to fp16,
+                        fp32 accumulation (v_mfma_f32_32x32x16_f16); everything else fp32.
+                        Tolerance re-stated: see DESIGN.md */
 };
 
 /* ---- models ------------------------------------------------------------------------------ */
@@ -97,6 +100,10 @@ int pn_kernel_count(void);
 const char *pn_kernel_name(int i);
 int pn_ctx_kernel_time(pn_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
 int pn_ctx_reset_profile(pn_ctx *ctx);
+
+/* Debug tap (tests/tools): copy an internal device buffer to the host; which = 0 feat, 1 c1ring,
+   2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r.  Returns bytes copied or -1. */
+long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_bytes);
 
 const char *pn_last_error(void);
 const char *pn_version(void);

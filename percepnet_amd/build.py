@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpercepnet_hip.so")
 RUN = os.path.join(LIBDIR, "percepnet_run")
-SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_nn.hip", "pn_context.cpp", "rnnoise_compat.cpp"]
+SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_f16.hip", "pn_context.cpp", "rnnoise_compat.cpp"]
 # percepnet_run.cpp (the CLI) is linked separately against the library
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]

@@ -9,7 +9,7 @@
 #define PN_FREQ 481
 #define PN_NB 34
 #define PN_NFEAT 70
-#define PN_FEAT_STRIDE 96       // features padded with zeros to a multiple of the GEMM K-tile (32)
+#define PN_FEAT_STRIDE 128      // features padded with zeros to a multiple of the GEMM K-tiles (32 fp32 / 64 fp16)
 #define PN_NFFT 960
 #define PN_HIST_FRAMES 12       // comb_buf = 5760 samples = 12 frames (denoise.cpp:32), kept as a ring
 #define PN_HIST (PN_HIST_FRAMES * PN_FRAME)

@@ -17,8 +17,14 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_
                         int *silence, int *last_period, float *last_gain);
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
-size_t pn_packed_floats(int K, int ncols, int ct_round);
-void pn_pack_weights(const float *W, int K, int ncols, int ct_round, float *Wp);
+size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
+void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
+size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);
+void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);
+void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, int n_rows);
+void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, const float *h_old, const void *Wp, const void *Up,
+                       const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
 int pn_dense_nt(int N);
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows);
@@ -207,7 +213,7 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
 extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
-  if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
+  if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     pn_set_error("no HIP device available (this library has no CPU fallback)");
@@ -265,16 +271,30 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
       if (nr && upload(c, &c->L[li].rw, H.rw, nr)) goto fail;
     } else {
       const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
+      const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
       const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
-      std::vector<float> packed(pn_packed_floats(K, ncols, ctr));
-      pn_pack_weights(H.w, K, ncols, ctr, packed.data());
-      if (upload(c, &c->L[li].wp, packed.data(), packed.size())) goto fail;
-      if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
-      if (nr) {
-        std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
-        pn_pack_weights(H.rw, H.nn, ncols, 1, rp.data());
-        if (upload(c, &c->L[li].rwp, rp.data(), rp.size())) goto fail;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+      if (nn_mode == PN_NN_MFMA_F16) {
+        std::vector<uint16_t> packed(pn_packed_halfs(k_alloc, ncols, ctr));
+        pn_pack_weights_f16(H.w, K, k_alloc, ncols, ctr, packed.data());
+        if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
+        if (nr) {
+          std::vector<uint16_t> rp(pn_packed_halfs(H.nn, ncols, 1));
+          pn_pack_weights_f16(H.rw, H.nn, H.nn, ncols, 1, rp.data());
+          if (upload(c, &c->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+        }
+      } else {
+        std::vector<float> packed(pn_packed_floats(k_alloc, ncols, ctr));
+        pn_pack_weights(H.w, K, k_alloc, ncols, ctr, packed.data());
+        if (upload(c, &c->L[li].wp, packed.data(), packed.size())) goto fail;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
+        if (nr) {
+          std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
+          pn_pack_weights(H.rw, H.nn, H.nn, ncols, 1, rp.data());
+          if (upload(c, &c->L[li].rwp, rp.data(), rp.size())) goto fail;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+        }
       }
     }
   }
@@ -335,28 +355,33 @@ static PnSegs seg1(const float *p, int ld, int width) { PnSegs s; memset(&s, 0, 
 // compute_rnn (rnn.cpp:42-81) for all streams; features in c->feat, result in c->gr
 static void launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
+  const bool f16 = c->nn_mode == PN_NN_MFMA_F16;
   hipStream_t st = c->stream; const float *tab = c->tansig;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
   float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128;
   float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512;
   { Scope sc(c, KF_FC);
-    PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..95 are zero
-    pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B); }
+    PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
+    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B);
+    else pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B); }
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B); }
+    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B);
+    else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B); }
+    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B);
+    else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B); }
   const float *x = c->c2out;
   for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
     Scope sc(c, KF_GRU512);
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
+    if (f16) pn_launch_gru_f16(st, X, ho, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
+    else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
     x = hn;
   }
   const float *g1 = c->gru[0] + (size_t)nxt * Bp * 512, *g2 = c->gru[1] + (size_t)nxt * Bp * 512,
@@ -366,15 +391,18 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B); }
+    if (f16) pn_launch_gru_f16(st, X, rbo, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B);
+    else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B); }
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B); }
+    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
+    else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B); }
   { Scope sc(c, KF_FC_RB);
     PnSegs A = seg1(rbn, 128, 128);
-    pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B); }
+    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
+    else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B); }
 }
 
 static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16) {
@@ -441,7 +469,7 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
 }
 
 // Debug tap (tests/tools only): copy an internal device buffer to the host.
-// which: 0 feat[B][96], 1 c1ring[5][B][128], 2 c2ring[3][B][512], 3 c2out[B][512],
+// which: 0 feat[B][128], 1 c1ring[5][B][128], 2 c2ring[3][B][512], 3 c2out[B][512],
 //        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68].  Returns the byte count.
 extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long long max_bytes) {
   if (!c || !dst) return -1;

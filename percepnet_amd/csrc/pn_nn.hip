@@ -20,14 +20,10 @@
 //
 // STRICT path (PN_NN_STRICT): one lane per (stream, neuron), separate v_mul/v_add in the
 // reference's order (file compiled with -ffp-contract=off) — bit-identical to the CPU reference.
-#include "pn_common.h"
+#include "pn_nn_common.h"
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-#define BM 128
 #define BK 32
 #define LDT 36            // padded LDS row stride (floats)
-#define NN_THREADS 256
 // timing experiments only (results become wrong): -DPN_EXP_NOBARRIER, -DPN_EXP_NOSTAGE, -DPN_EXP_NODRAIN
 #if defined(PN_EXP_NOSTAGE) || defined(PN_EXP_NOLOAD)
 #define PN_STAGE_LD(x) do {} while (0)
@@ -44,57 +40,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #else
 #define PN_SYNC() __syncthreads()
 #endif
-
-struct PnSegs {           // A operand = concatenation along K of up to 5 row-major panels
-  const float *p[5];
-  int ld[5];              // row stride (floats)
-  int width[5];           // valid columns; the MFMA path requires every panel to be readable (and
-                          // zero) up to the next multiple of 32 and all panels to be equally wide
-  int n;
-};
-
-enum { ACT_LINEAR = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_RELU = 3 };
-
-// panel pointer by (uniform) index without dynamically indexing the by-value kernel argument
-// (a runtime index would spill the whole struct to scratch)
-#define PN_PANEL_ARGS const float *pp0, const float *pp1, const float *pp2, const float *pp3, const float *pp4, int pld
-#define PN_PANEL_PASS pp0, pp1, pp2, pp3, pp4, pld
-#define PN_PANEL_LOCALS(A) const float *pp0 = (A).p[0], *pp1 = (A).p[1], *pp2 = (A).p[2], *pp3 = (A).p[3], \
-                           *pp4 = (A).p[4]; const int pld = (A).ld[0]
-__device__ __forceinline__ const float *pn_seg_ptr(PN_PANEL_ARGS, int sg) {
-  (void)pld;
-  const float *p = pp0;
-  p = sg == 1 ? pp1 : p;
-  p = sg == 2 ? pp2 : p;
-  p = sg == 3 ? pp3 : p;
-  p = sg == 4 ? pp4 : p;
-  return p;
-}
-
-// tansig_approx / sigmoid_approx (reference vec.h:53-75)
-__device__ __forceinline__ float pn_tansig(float x, const float *tab) {
-  float sign = 1;
-  if (x < 0) { x = -x; sign = -1; }
-  const float v = floorf(.5f + 25 * x);
-  // the reference's x86-64 build converts with cvttss2si: out-of-range / NaN -> INT_MIN, which
-  // the clamp below then turns into index 0 (not 200); mirrored here so that even absurd
-  // pre-activations (> 8.6e7) behave like the CPU path
-  int i = (v < 2147483648.f) ? (int)v : (int)0x80000000;
-  i = i > 200 ? 200 : i;
-  i = i < 0 ? 0 : i;
-  x -= .04f * i;
-  float y = tab[i];
-  const float dy = 1 - y * y;
-  y = y + x * dy * (1 - y * x);
-  return sign * y;
-}
-__device__ __forceinline__ float pn_sigmoid(float x, const float *tab) { return .5f + .5f * pn_tansig(.5f * x, tab); }
-__device__ __forceinline__ float pn_act(float v, int act, const float *tab) {
-  if (act == ACT_SIGMOID) return pn_sigmoid(v, tab);
-  if (act == ACT_TANH) return pn_tansig(v, tab);
-  if (act == ACT_RELU) return v < 0 ? 0 : v;
-  return v;
-}
 
 // =============================== STRICT kernels ==================================================
 // W in the reference layout [K][ncols] (nnet_data.h); thread = (stream blockIdx.y, neuron).
@@ -196,22 +141,6 @@ __device__ __forceinline__ void pn_store_B(float (*Bs)[LDT], const float4 &v) {
   *reinterpret_cast<float4 *>(&Bs[tid >> 3][4 * (tid & 7)]) = v;
 }
 
-// Toolchain hazard found on ROCm 7.2 / gfx950 (DESIGN.md "MFMA result hazard"): when a loop of
-// v_mfma_f32_32x32x2_f32 exits, hipcc places the first read of the accumulator tuple (a
-// v_accvgpr_mov of element 15, the register the 16th pass writes last) only `s_nop 1` after the
-// final MFMA, and that read returns the value from BEFORE it: output rows 27/31 (mod 32) silently
-// lose the last k-step.  The hazard recogniser does not look across the loop back-edge / exit
-// copies.  Every K-tile therefore ends with an explicit drain of the matrix pipe (32 wait states
-// >= the 19 a 16-pass MFMA needs), pinned in place with scheduling barriers: ~1 % of a K-tile.
-__device__ __forceinline__ void pn_mfma_drain() {
-#ifdef PN_EXP_NODRAIN
-  return;
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 template <int NT>
 __device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
                                              int wave, int lane) {
@@ -235,15 +164,6 @@ __device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float
     for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
   }
   pn_mfma_drain();
-}
-
-// XCD-aware block numbering: hardware places block b on XCD b % 8; give each XCD whole
-// activation panels (all column tiles of an M tile run on the same XCD's L2).
-__device__ __forceinline__ bool pn_tile_of_block(int n_mtiles, int n_ctiles, int &mt, int &ct) {
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  mt = (idx / n_ctiles) * 8 + xcd;
-  ct = idx % n_ctiles;
-  return mt < n_mtiles;
 }
 
 // Register set holding one prefetched K-tile (A: 4 float4, B: up to NB float4 per thread)
@@ -625,11 +545,12 @@ static inline int pn_ct_padded(int ncols, int ct_round) {
   const int CT = (ncols + 31) / 32;
   return ((CT + ct_round - 1) / ct_round) * ct_round;
 }
-size_t pn_packed_floats(int K, int ncols, int ct_round) {
-  return (size_t)pn_ct_padded(ncols, ct_round) * ((K + 31) / 32) * 1024;
+// k_alloc >= K: number of K rows the kernel will sweep (the zero-padded panel width)
+size_t pn_packed_floats(int k_alloc, int ncols, int ct_round) {
+  return (size_t)pn_ct_padded(ncols, ct_round) * ((k_alloc + 31) / 32) * 1024;
 }
-void pn_pack_weights(const float *W, int K, int ncols, int ct_round, float *Wp) {
-  const int CT = pn_ct_padded(ncols, ct_round), KT = (K + 31) / 32;
+void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp) {
+  const int CT = pn_ct_padded(ncols, ct_round), KT = (k_alloc + 31) / 32;
   for (int ct = 0; ct < CT; ct++)
     for (int kt = 0; kt < KT; kt++) {
       float *tile = Wp + ((size_t)ct * KT + kt) * 1024;

@@ -1,0 +1,85 @@
+// Shared device helpers of the network kernels (pn_nn.hip: fp32 MFMA + STRICT, pn_nn_f16.hip: fp16-input MFMA).
+#pragma once
+#include "pn_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define BM 128            // streams per block tile
+#define NN_THREADS 256
+
+struct PnSegs {           // A operand = concatenation along K of up to 5 row-major panels
+  const float *p[5];
+  int ld[5];              // row stride (floats)
+  int width[5];           // valid columns; the MFMA path requires every panel to be readable (and
+                          // zero) up to the next multiple of 32 and all panels to be equally wide
+  int n;
+};
+
+enum { ACT_LINEAR = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_RELU = 3 };
+
+// panel pointer by (uniform) index without dynamically indexing the by-value kernel argument
+// (a runtime index would spill the whole struct to scratch)
+#define PN_PANEL_ARGS const float *pp0, const float *pp1, const float *pp2, const float *pp3, const float *pp4, int pld
+#define PN_PANEL_PASS pp0, pp1, pp2, pp3, pp4, pld
+#define PN_PANEL_LOCALS(A) const float *pp0 = (A).p[0], *pp1 = (A).p[1], *pp2 = (A).p[2], *pp3 = (A).p[3], \
+                           *pp4 = (A).p[4]; const int pld = (A).ld[0]
+__device__ __forceinline__ const float *pn_seg_ptr(PN_PANEL_ARGS, int sg) {
+  (void)pld;
+  const float *p = pp0;
+  p = sg == 1 ? pp1 : p;
+  p = sg == 2 ? pp2 : p;
+  p = sg == 3 ? pp3 : p;
+  p = sg == 4 ? pp4 : p;
+  return p;
+}
+
+// tansig_approx / sigmoid_approx (reference vec.h:53-75)
+__device__ __forceinline__ float pn_tansig(float x, const float *tab) {
+  float sign = 1;
+  if (x < 0) { x = -x; sign = -1; }
+  const float v = floorf(.5f + 25 * x);
+  // the reference's x86-64 build converts with cvttss2si: out-of-range / NaN -> INT_MIN, which
+  // the clamp below then turns into index 0 (not 200); mirrored here so that even absurd
+  // pre-activations (> 8.6e7) behave like the CPU path
+  int i = (v < 2147483648.f) ? (int)v : (int)0x80000000;
+  i = i > 200 ? 200 : i;
+  i = i < 0 ? 0 : i;
+  x -= .04f * i;
+  float y = tab[i];
+  const float dy = 1 - y * y;
+  y = y + x * dy * (1 - y * x);
+  return sign * y;
+}
+__device__ __forceinline__ float pn_sigmoid(float x, const float *tab) { return .5f + .5f * pn_tansig(.5f * x, tab); }
+__device__ __forceinline__ float pn_act(float v, int act, const float *tab) {
+  if (act == ACT_SIGMOID) return pn_sigmoid(v, tab);
+  if (act == ACT_TANH) return pn_tansig(v, tab);
+  if (act == ACT_RELU) return v < 0 ? 0 : v;
+  return v;
+}
+
+// Toolchain hazard found on ROCm 7.2 / gfx950 (DESIGN.md "MFMA result hazard"): when a loop of
+// v_mfma_f32_32x32x2_f32 exits, hipcc places the first read of the accumulator tuple (a
+// v_accvgpr_mov of element 15, the register the 16th pass writes last) only `s_nop 1` after the
+// final MFMA, and that read returns the value from BEFORE it: output rows 27/31 (mod 32) silently
+// lose the last k-step.  The hazard recogniser does not look across the loop back-edge / exit
+// copies.  Every K-tile therefore ends with an explicit drain of the matrix pipe (32 wait states
+// >= the 19 a 16-pass MFMA needs), pinned in place with scheduling barriers: ~1 % of a K-tile.
+__device__ __forceinline__ void pn_mfma_drain() {
+#ifdef PN_EXP_NODRAIN
+  return;
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// XCD-aware block numbering: hardware places block b on XCD b % 8; give each XCD whole
+// activation panels (all column tiles of an M tile run on the same XCD's L2).
+__device__ __forceinline__ bool pn_tile_of_block(int n_mtiles, int n_ctiles, int &mt, int &ct) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  mt = (idx / n_ctiles) * 8 + xcd;
+  ct = idx % n_ctiles;
+  return mt < n_mtiles;
+}
+

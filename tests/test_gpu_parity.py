@@ -19,6 +19,11 @@ pytestmark = pytest.mark.gpu
 
 PCM_TOL_LSB = 1
 GR_TOL = 2e-5
+# BASELINE configs[4] (fp16 GEMM operands, fp32 accumulation): north_star asks for the tolerance to be
+# re-stated.  Measured on MI355X over 24 streams x 100 frames: max 3 LSB (loud streams), 1 LSB on
+# normal-level streams, 8% of samples differ at all; g/r max 2.3e-4, mean 3.5e-5.
+F16_PCM_TOL_LSB = 4
+F16_GR_TOL = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -115,6 +120,22 @@ def test_mfma_mode_within_one_lsb(model, oracle):
     d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
     assert d.max() <= PCM_TOL_LSB, d.max()
     assert np.abs(gr - rg).max() <= GR_TOL, np.abs(gr - rg).max()
+    ctx.close()
+
+
+def test_fp16_variant_tolerance(model, oracle):
+    """configs[4]: fp16 weights/activations as MFMA operands, fp32 accumulate/state/DSP."""
+    B, T = 24, 100
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA_F16)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, pcm)
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    assert d.max() <= F16_PCM_TOL_LSB, d.max()
+    assert np.abs(gr - rg).max() <= F16_GR_TOL, np.abs(gr - rg).max()
+    assert np.abs(gr - rg).mean() <= 1e-4
+    feat, _ = ctx.read_features()            # the DSP front end does not depend on the network mode
+    assert np.isfinite(feat).all()
     ctx.close()
 
 

@@ -7,7 +7,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
 model = api.Model(weights.default_blob(1234))
-ctx = api.Context(model, B, stream=torch.cuda.current_stream().cuda_stream)
+MODE = {'f32': api.NN_MFMA, 'f16': api.NN_MFMA_F16, 'strict': api.NN_STRICT}[os.environ.get('PN_MODE', 'f32')]
+ctx = api.Context(model, B, nn_mode=MODE, stream=torch.cuda.current_stream().cuda_stream)
 P = min(B, 64); T = K + 2
 pool = torch.from_numpy(synth.synth_batch(P, T)).to(dev)
 idx = torch.arange(B, device=dev) % P
@@ -19,5 +20,5 @@ t0 = time.perf_counter()
 for t in range(2, T): ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 kt = ctx.kernel_times()
-print(os.environ.get("PERCEPNET_LIB", "default").split("/")[-2:][0], f"B={B} ms/step={1e3*dt/K:.3f} streams={B*K/dt/100:.0f} |",
+print(os.environ.get("PERCEPNET_LIB", "default").split("/")[-2:][0], os.environ.get("PN_MODE", "f32"), f"B={B} ms/step={1e3*dt/K:.3f} streams={B*K/dt/100:.0f} |",
       " ".join(f"{k}={v[0]/max(v[1],1):.3f}" for k, v in kt.items()))
