@@ -105,6 +105,37 @@ int pn_ctx_reset_profile(pn_ctx *ctx);
    2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r.  Returns bytes copied or -1. */
 long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_bytes);
 
+/* ---- batched training-feature generator ----------------------------------- */
+/* The reference's `percepNet <speech> <noisy> <count> <output>` binary (train(), denoise.cpp:603-787,
+   declared rnnoise.h:66) for n_pairs (speech, noisy) pairs in lock-step.  Samples are int16 at
+   NORM_RATIO 1 (denoise.cpp:41,697: the float sample IS the int16 value).  One record = 138 float32:
+   Ey_lookahead[34] | Ephaty[34] | T | pitch_corr | g[34] | r[34] (denoise.cpp:764-773), g being
+   envelope-post-filtered as in the reference's default (TEST) build (45-47, 743).  The optional PCM is
+   that build's test_output.pcm.  No model is involved. */
+typedef struct pn_featgen pn_featgen;
+pn_featgen *pn_featgen_create(int device, int n_pairs, void *hip_stream);
+void pn_featgen_destroy(pn_featgen *fg);
+int pn_featgen_reset(pn_featgen *fg);
+int pn_featgen_n_pairs(const pn_featgen *fg);
+int64_t pn_featgen_frames_done(const pn_featgen *fg);
+size_t pn_featgen_device_bytes(const pn_featgen *fg);
+int pn_featgen_synchronize(pn_featgen *fg);
+/* One frame, device buffers, asynchronous: speech/noisy [n_pairs][480]; records [n_pairs][138];
+   test_pcm (may be NULL) [n_pairs][480]. */
+int pn_featgen_process_i16(pn_featgen *fg, const int16_t *d_speech, const int16_t *d_noisy, float *d_records,
+                           int16_t *d_test_pcm);
+/* n_frames frames, pair-major "file images": speech/noisy [n_pairs][n_frames][480], records
+   [n_pairs][n_frames][138] (= each pair's output file), test_pcm [n_pairs][n_frames][480] or NULL. */
+int pn_featgen_process_i16_files(pn_featgen *fg, const int16_t *d_speech, const int16_t *d_noisy, int n_frames,
+                                 float *d_records, int16_t *d_test_pcm);
+int pn_featgen_process_host_i16_files(pn_featgen *fg, const int16_t *h_speech, const int16_t *h_noisy, int n_frames,
+                                      float *h_records, int16_t *h_test_pcm);
+/* File-level driver with train()'s file semantics (whole frames cycled at EOF, 693-715) for n_jobs
+   jobs at once; test_out_paths / test_in_paths may be NULL (or hold NULL entries). */
+int pn_featgen_run_files(int device, int n_jobs, const char *const *speech_paths, const char *const *noisy_paths,
+                         const int *counts, const char *const *out_paths, const char *const *test_out_paths,
+                         const char *const *test_in_paths);
+
 const char *pn_last_error(void);
 const char *pn_version(void);
 
@@ -116,6 +147,7 @@ int rnnoise_init_c(DenoiseState *st, RNNModel *model);
 DenoiseState *rnnoise_create_c(RNNModel *model);
 void rnnoise_destroy_c(DenoiseState *st);
 float rnnoise_process_frame_c(DenoiseState *st, float *out, const float *in, FILE *f_feature);
+int rnnoise_train_c(int argc, char **argv);            /* train(), rnnoise.h:66 */
 RNNModel *rnnoise_model_from_file_c(FILE *f);
 void rnnoise_model_free_c(RNNModel *model);
 

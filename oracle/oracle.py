@@ -91,6 +91,17 @@ class Oracle:
         self.lib.pno_destroy(st)
         return feat, sil
 
+    def train_run(self, speech, noisy, want_test_pcm=True):
+        """The `percepNet` training binary on in-memory PCM -> (records [count,138], test_output [count,480])."""
+        speech = np.ascontiguousarray(speech, dtype=np.int16); noisy = np.ascontiguousarray(noisy, dtype=np.int16)
+        n = min(speech.size, noisy.size) // 480
+        out = np.zeros((n, 138), np.float32)
+        tst = np.zeros((n, 480), np.int16)
+        self.lib.pno_train_run.argtypes = [c_s, c_s, ctypes.c_int, c_f, c_s]
+        self.lib.pno_train_run(speech.ctypes.data_as(c_s), noisy.ctypes.data_as(c_s), n, _fp(out),
+                               tst.ctypes.data_as(c_s) if want_test_pcm else None)
+        return out, tst
+
     def tables(self):
         tw = c_f(); br = c_s(); hw = c_f(); ch = c_f(); bd = c_i()
         self.lib.pno_tables(ctypes.byref(tw), ctypes.byref(br), ctypes.byref(hw), ctypes.byref(ch),
@@ -144,3 +155,22 @@ class Reference:
         gr = np.zeros((n, 68), np.float32)
         self.lib.ref_run_float(_fp(x), n, _fp(out), _fp(gr))
         return out, gr
+
+    def train(self, speech, noisy, workdir):
+        """Run the reference's train() (denoise.cpp:603-787) on two PCM arrays through real files in
+        workdir, as the binary does: returns (records [count,138], test_output.pcm [count,480])."""
+        speech = np.ascontiguousarray(speech, dtype=np.int16); noisy = np.ascontiguousarray(noisy, dtype=np.int16)
+        n = min(speech.size, noisy.size) // 480
+        sp, no, ou = (os.path.join(workdir, f) for f in ("speech.pcm", "noisy.pcm", "features.f32"))
+        speech.tofile(sp); noisy.tofile(no)
+        self.lib.ref_train.argtypes = [ctypes.c_char_p] * 4
+        cwd = os.getcwd()
+        os.chdir(workdir)           # train() drops test_input.pcm / test_output.pcm into the cwd
+        try:
+            rc = self.lib.ref_train(sp.encode(), no.encode(), str(n).encode(), ou.encode())
+        finally:
+            os.chdir(cwd)
+        assert rc == 0, rc
+        rec = np.fromfile(ou, np.float32).reshape(n, 138)
+        tst = np.fromfile(os.path.join(workdir, "test_output.pcm"), np.int16).reshape(n, 480)
+        return rec, tst

@@ -673,3 +673,112 @@ void pno_run_float(const pno_model *m, const float *in, int n_frames, float *out
     pno_process_frame(st, out + (size_t)t * FRAME, in + (size_t)t * FRAME, gr ? gr + (size_t)t * 68 : NULL);
   pno_destroy(st);
 }
+
+
+/* ================================================================== training-feature generator
+ * one iteration of the `percepNet` binary's train() loop, denoise.cpp:655-778,
+ * as the reference's default build runs it (TEST defined at denoise.cpp:45-47, so the ideal gains
+ * ARE envelope-post-filtered before they are written; the random gain/response block 673-691 and
+ * the biquads 717-720 are commented out in the reference; NORM_RATIO 1, denoise.cpp:41). */
+struct pno_train { pno_state *clean, *noisy; float pna, n0; };
+
+pno_train *pno_train_create(void) {
+  pno_train *tr = (pno_train *)calloc(1, sizeof(*tr)); int i;
+  tr->clean = pno_create(NULL); tr->noisy = pno_create(NULL);
+  tr->pna = 0;                                              /* denoise.cpp:207-210 */
+  for (i = 1; i < COMB_M * 2 + 2; i++) tr->pna += g_comb_hann[i - 1] * g_comb_hann[i - 1];
+  tr->n0 = 0.03;                                            /* denoise.cpp:211 */
+  return tr;
+}
+void pno_train_destroy(pno_train *tr) { if (tr) { pno_destroy(tr->clean); pno_destroy(tr->noisy); free(tr); } }
+
+/* post_filtering denoise.cpp:216-250 */
+static void post_filtering(float *g, const float *Ey) {
+  int i; float E0 = 0, E1 = 0, E_div, G, g_w[NB];
+  for (i = 0; i < NB; i++) g_w[i] = g[i] * sinf(M_PI / 2 * g[i]);
+  for (i = 0; i < NB; i++) E0 += g[i] * Ey[i];
+  for (i = 0; i < NB; i++) E1 += g_w[i] * Ey[i];
+  E_div = E0 / (E1 + 1e-6f);
+  G = sqrtf(((1 + 0.02f) * E_div) / (1 + 0.02f * (E_div * E_div)));
+  for (i = 0; i < NB; i++) g[i] = G * g_w[i];
+}
+
+/* x = speech frame, n = noisy frame (float(int16), NORM_RATIO 1).  out138 = the record train()
+   appends to <output> (764-773).  test_out480 (may be NULL) = the TEST synthesis `out[]` (743-757)
+   before the saturating short cast.  Float/double promotion follows the C++ overloads the
+   reference resolves to (sqrt(float) -> float; pow(float,int) -> double). */
+void pno_train_frame(pno_train *tr, const float *x, const float *n, float *out138, float *test_out480) {
+  frame_ana Y, X; float g[NB], r[NB], Ephatp[NB], Ey_look[NB]; int i;
+  const float *Ephaty = Y.Exp, *Exp = X.Exp;
+  frame_features(tr->noisy, &Y, n);                         /* 730 */
+  frame_features(tr->clean, &X, x);                         /* 731 */
+  for (i = 0; i < NB; i++) {                                /* calc_ideal_gain 571-577 */
+    g[i] = X.Ex[i] / (.0001 + Y.Ex[i]);
+    if (g[i] > 1) g[i] = 1;
+    if (g[i] < 0) g[i] = 0;
+  }
+  /* 733-734 compute Eyp = corr(Y, P) which nothing reads afterwards (filter_strength_calc is handed
+     Ephaty in its place, 736): dead, skipped */
+  for (i = 0; i < NB; i++)                                  /* estimate_phat_corr 549-553 */
+    Ephatp[i] = Ephaty[i] / sqrt((1 - tr->pna) * pow(Ephaty[i], 2) + tr->pna);
+  for (i = 0; i < NB; i++) {                                /* filter_strength_calc 555-569 */
+    float a = Ephatp[i] * Ephatp[i] - Exp[i] * Exp[i], b, c, alpha;
+    if (a < 0) a = 0;
+    b = Ephatp[i] * Ephaty[i] * (1 - Exp[i] * Exp[i]);
+    c = Exp[i] * Exp[i] - Ephaty[i] * Ephaty[i];
+    if (c < 0) c = 0;
+    alpha = (sqrtf(b * b + a * (c)) - b) / (a + 1e-8);
+    r[i] = alpha / (1 + alpha);
+  }
+  for (i = 0; i < NB; i++)                                  /* adjust_gain_strength_by_condition 579-589 */
+    if (Ephatp[i] < Exp[i]) {
+      float g_att = sqrtf((1 + tr->n0 - Exp[i] * Exp[i]) / (1 + tr->n0 - Ephatp[i] * Ephatp[i]));
+      r[i] = 0.99;
+      g[i] *= g_att;
+    }
+  post_filtering(g, Y.Ex);                                  /* 743 (TEST) */
+  {                                                         /* 744-757 (TEST): synthesis through st */
+    float gf[FREQ], rf[FREQ], inv_r[NB], t[WINDOW]; cpx xx[WINDOW], yy[WINDOW];
+    if (!Y.silence) {
+      for (i = 0; i < FREQ; i++) rf[i] = 0;
+      for (i = 0; i < NB; i++) inv_r[i] = 1 - r[i];
+      interp_band_gain(rf, inv_r);
+      for (i = 0; i < FREQ; i++) { Y.X[i].r = rf[i] * Y.X[i].r; Y.X[i].i = rf[i] * Y.X[i].i; }
+      interp_band_gain(rf, r);
+      for (i = 0; i < FREQ; i++) { Y.X[i].r += rf[i] * Y.P[i].r; Y.X[i].i += rf[i] * Y.P[i].i; }
+    }
+    for (i = 0; i < FREQ; i++) gf[i] = 0;
+    interp_band_gain(gf, g);
+    for (i = 0; i < FREQ; i++) { Y.X[i].r *= gf[i]; Y.X[i].i *= gf[i]; }
+    for (i = 0; i < FREQ; i++) xx[i] = Y.X[i];
+    for (; i < WINDOW; i++) { xx[i].r = xx[WINDOW - i].r; xx[i].i = -xx[WINDOW - i].i; }
+    fft960(xx, yy);
+    t[0] = WINDOW * yy[0].r;
+    for (i = 1; i < WINDOW; i++) t[i] = WINDOW * yy[WINDOW - i].r;
+    for (i = 0; i < FRAME; i++) { t[i] *= g_half_window[i]; t[WINDOW - 1 - i] *= g_half_window[i]; }
+    if (test_out480) for (i = 0; i < FRAME; i++) test_out480[i] = t[i] + tr->clean->synthesis_mem[i];
+    memcpy(tr->clean->synthesis_mem, t + FRAME, FRAME * sizeof(float));
+  }
+  {                                                         /* compute_lookahead_band_energy(noisy) 760 */
+    cpx L[FREQ];
+    window_fft(L, tr->noisy->comb_buf + COMB_BUF - WINDOW);
+    band_energy(Ey_look, L);
+  }
+  memcpy(out138, Ey_look, sizeof(Ey_look));                 /* 764-773 */
+  memcpy(out138 + NB, Ephaty, NB * sizeof(float));
+  out138[68] = (float)tr->noisy->last_period / (PITCH_MAX - 3 * PITCH_MIN);
+  out138[69] = tr->noisy->pitch_corr;
+  memcpy(out138 + 70, g, sizeof(g));
+  memcpy(out138 + 70 + NB, r, sizeof(r));
+}
+
+/* the whole binary on in-memory PCM (both inputs at least count frames long: no rewind) */
+void pno_train_run(const short *speech, const short *noisy, int count, float *out, short *test_out) {
+  pno_train *tr = pno_train_create(); float x[FRAME], n[FRAME], to[FRAME]; int t, i;
+  for (t = 0; t < count; t++) {
+    for (i = 0; i < FRAME; i++) { x[i] = (float)speech[(size_t)t * FRAME + i]; n[i] = (float)noisy[(size_t)t * FRAME + i]; }
+    pno_train_frame(tr, x, n, out + (size_t)t * 138, to);
+    if (test_out) for (i = 0; i < FRAME; i++) test_out[(size_t)t * FRAME + i] = (short)fmax(-32768, fmin(32767, to[i]));
+  }
+  pno_train_destroy(tr);
+}

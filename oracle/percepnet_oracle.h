@@ -53,6 +53,14 @@ void pno_dense(const float *bias, const float *w, int nin, int nn, int act, floa
 void pno_conv1d(const float *bias, const float *w, int nin, int ks, int nn, int act, float *out, float *mem, const float *in);
 void pno_gru(const float *bias, const float *w, const float *rw, int nin, int nn, int act, float *state, const float *in);
 
+
+/* ---- the `percepNet` training-feature binary (train(), denoise.cpp:603-787) ---- */
+typedef struct pno_train pno_train;
+pno_train *pno_train_create(void);
+void pno_train_destroy(pno_train *tr);
+void pno_train_frame(pno_train *tr, const float *x480, const float *n480, float *out138, float *test_out480);
+void pno_train_run(const short *speech, const short *noisy, int count, float *out138xcount, short *test_out);
+
 #ifdef __cplusplus
 }
 #endif

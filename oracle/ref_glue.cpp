@@ -160,4 +160,11 @@ void ref_gru(const float *bias, const float *w, const float *rw, int nin, int nn
   GRULayer L = {bias, w, rw, nin, nn, act, 1}; compute_gru(&L, state, in);
 }
 
+/* The `percepNet` training binary's body (denoise.cpp:603-787) with its own argv contract
+ * (<speech> <noisy> <count> <output>); it also drops test_input.pcm/test_output.pcm into the cwd. */
+int ref_train(const char *speech, const char *noisy, const char *count, const char *output) {
+  char *argv[5] = {(char*)"percepNet", (char*)speech, (char*)noisy, (char*)count, (char*)output};
+  return train(5, argv);
+}
+
 } /* extern "C" */

@@ -65,6 +65,17 @@ def load_library():
     L.pn_ctx_kernel_time.argtypes = [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_int64)]
     L.pn_ctx_reset_profile.argtypes = [_vp]
+    L.pn_featgen_create.restype = _vp
+    L.pn_featgen_create.argtypes = [ctypes.c_int, ctypes.c_int, _vp]
+    L.pn_featgen_destroy.argtypes = [_vp]
+    L.pn_featgen_reset.argtypes = [_vp]
+    L.pn_featgen_synchronize.argtypes = [_vp]
+    L.pn_featgen_device_bytes.restype = ctypes.c_size_t
+    L.pn_featgen_device_bytes.argtypes = [_vp]
+    L.pn_featgen_process_i16.argtypes = [_vp, _vp, _vp, _vp, _vp]
+    L.pn_featgen_process_i16_files.argtypes = [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]
+    L.pn_featgen_process_host_i16_files.argtypes = [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]
+    L.pn_featgen_run_files.argtypes = [ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     _lib = L
     return L
 
@@ -193,3 +204,72 @@ class Context:
             self._chk(self.L.pn_ctx_kernel_time(self.h, name, ctypes.byref(ms), ctypes.byref(n)))
             out[name.decode()] = (ms.value, n.value)
         return out
+
+
+class FeatGen:
+    """Batched training-feature generator (pn_featgen): the reference's `percepNet <speech> <noisy>
+    <count> <output>` binary (train(), denoise.cpp:603-787) for n_pairs pairs in lock-step."""
+
+    def __init__(self, n_pairs, device=0, stream=None):
+        self.L = load_library()
+        self.n_pairs = int(n_pairs)
+        self.h = self.L.pn_featgen_create(device, self.n_pairs, stream)
+        if not self.h:
+            raise PercepNetError(_err(self.L))
+
+    def close(self):
+        if self.h:
+            self.L.pn_featgen_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PercepNetError(_err(self.L))
+
+    def reset(self):
+        self._chk(self.L.pn_featgen_reset(self.h))
+
+    def synchronize(self):
+        self._chk(self.L.pn_featgen_synchronize(self.h))
+
+    def device_bytes(self):
+        return self.L.pn_featgen_device_bytes(self.h)
+
+    def process_dev(self, d_speech, d_noisy, d_records, d_test_pcm=None):
+        """One frame; device pointers (ints): [n_pairs][480] i16 x2 -> [n_pairs][138] f32 (+ [n_pairs][480] i16)."""
+        self._chk(self.L.pn_featgen_process_i16(self.h, d_speech, d_noisy, d_records, d_test_pcm))
+
+    def process_files_dev(self, d_speech, d_noisy, n_frames, d_records, d_test_pcm=None):
+        self._chk(self.L.pn_featgen_process_i16_files(self.h, d_speech, d_noisy, n_frames, d_records, d_test_pcm))
+
+    def run(self, speech, noisy, want_test_pcm=True):
+        """speech, noisy: int16 [n_pairs, n_frames*480] -> (records [n_pairs, n_frames, 138] f32,
+        test_output [n_pairs, n_frames, 480] i16 or None).  Continues from the current state."""
+        speech = np.ascontiguousarray(speech, dtype=np.int16).reshape(self.n_pairs, -1)
+        noisy = np.ascontiguousarray(noisy, dtype=np.int16).reshape(self.n_pairs, -1)
+        n = min(speech.shape[1], noisy.shape[1]) // 480
+        speech = np.ascontiguousarray(speech[:, :n * 480]); noisy = np.ascontiguousarray(noisy[:, :n * 480])
+        rec = np.empty((self.n_pairs, n, 138), np.float32)
+        pcm = np.empty((self.n_pairs, n, 480), np.int16) if want_test_pcm else None
+        self._chk(self.L.pn_featgen_process_host_i16_files(self.h, speech.ctypes.data, noisy.ctypes.data, n,
+                                                           rec.ctypes.data, pcm.ctypes.data if want_test_pcm else None))
+        return rec, pcm
+
+
+def featgen_run_files(jobs, device=0, test_pcm=False):
+    """jobs: [(speech_path, noisy_path, count, output_path), ...] — pn_featgen_run_files."""
+    L = load_library()
+    n = len(jobs)
+    arr = lambda xs: (ctypes.c_char_p * n)(*[x.encode() if x is not None else None for x in xs])
+    sp, no, out = arr([j[0] for j in jobs]), arr([j[1] for j in jobs]), arr([j[3] for j in jobs])
+    cnt = (ctypes.c_int * n)(*[int(j[2]) for j in jobs])
+    to = arr([j[3] + ".test_output.pcm" for j in jobs]) if test_pcm else None
+    ti = arr([j[3] + ".test_input.pcm" for j in jobs]) if test_pcm else None
+    if L.pn_featgen_run_files(device, n, sp, no, cnt, out, to, ti) != 0:
+        raise PercepNetError(_err(L))

@@ -17,8 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpercepnet_hip.so")
 RUN = os.path.join(LIBDIR, "percepnet_run")
-SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_f16.hip", "pn_context.cpp", "rnnoise_compat.cpp"]
-# percepnet_run.cpp (the CLI) is linked separately against the library
+SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_f16.hip", "pn_targets.hip", "pn_context.cpp",
+           "pn_featgen.cpp", "rnnoise_compat.cpp"]
+# percepnet_run.cpp / percepnet_featgen.cpp (the CLIs) are linked separately against the library
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -78,13 +79,14 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    cli = os.path.join(CSRC, "percepnet_run.cpp")
-    if os.path.exists(cli) and (force or _stale(RUN, [cli, LIB])):
-        cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", cli, "-o", RUN, "-L" + LIBDIR,
-               "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for name in ("percepnet_run", "percepnet_featgen"):
+        cli, exe = os.path.join(CSRC, name + ".cpp"), os.path.join(LIBDIR, name)
+        if os.path.exists(cli) and (force or _stale(exe, [cli, LIB])):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", cli, "-o", exe, "-L" + LIBDIR,
+                   "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

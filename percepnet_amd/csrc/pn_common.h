@@ -10,6 +10,7 @@
 #define PN_NB 34
 #define PN_NFEAT 70
 #define PN_FEAT_STRIDE 128      // features padded with zeros to a multiple of the GEMM K-tiles (32 fp32 / 64 fp16)
+#define PN_AUX_STRIDE 72        // front-end side outputs for the training-feature path: Ep[34] | Exp[34] | pitch_corr
 #define PN_NFFT 960
 #define PN_HIST_FRAMES 12       // comb_buf = 5760 samples = 12 frames (denoise.cpp:32), kept as a ring
 #define PN_HIST (PN_HIST_FRAMES * PN_FRAME)
@@ -25,6 +26,7 @@ struct PnTables {
   float half_window[PN_FRAME];    // denoise.cpp:191-192
   float comb_hann[8];             // 7 used, denoise.cpp:200-206
   float tansig[208];              // 201 used, tansig_table.h
+  float pna, n0;                  // CommonState.power_noise_attenuation, .n0 (denoise.cpp:207-211)
   float bin_frac[PN_SPEC_BINS];   // (float)j / band_size for bin = border[i] + j
   int16_t bitrev[PN_NFFT];        // digit-reversal scatter index kiss_fft.cpp:315-345
   int16_t border[PN_NB + 2];      // ERBBand::nfftborder erbband.h:63-75

@@ -10,27 +10,7 @@
 #include <string>
 #include <vector>
 
-// ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
-struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
-void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
-                        int in_is_i16, float *hist, float2 *yring, float *eyring, float2 *Ps, float *feat,
-                        int *silence, int *last_period, float *last_gain);
-void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
-                       const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
-size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
-void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
-size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);
-void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);
-void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                         const float *tansig, float *out, int ldo, int n_rows);
-void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, const float *h_old, const void *Wp, const void *Up,
-                       const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
-int pn_dense_nt(int N);
-void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
-                     int N, int act, const float *tansig, float *out, int ldo, int n_rows);
-void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
-                   const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
-                   float *h_new, int n_rows);
+#include "pn_launch.h"
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -409,8 +389,8 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
   PN_HIP_CHECK(hipSetDevice(c->device));
   { Scope sc(c, KF_FRONTEND);
-    pn_launch_frontend(c->stream, c->tables, c->B, c->t, d_in, is_i16, c->hist, c->yring, c->eyring, c->Ps,
-                       c->feat, c->silence, c->last_period, c->last_gain); }
+    pn_launch_frontend(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring,
+                       c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr); }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
     // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6

@@ -355,14 +355,16 @@ __device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { r
 template <typename TIn>
 __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
-    const TIn *__restrict__ in,           // [n_streams][480]
+    const TIn *__restrict__ in,           // stream s's frame at in + s*in_stride (480 contiguous samples)
+    long long in_stride, float i16_scale, // int16 input: sample = (float)v * i16_scale (2^-15: main.cpp:34; 1: denoise.cpp:41,697)
     float *__restrict__ hist,             // [n_streams][12][480] ring
     float2 *__restrict__ yring,           // [6][n_streams][400] look-ahead spectra ring
     float *__restrict__ eyring,           // [6][n_streams][36]  look-ahead band energies ring
     float2 *__restrict__ Pspec,           // [n_streams][400]
     float *__restrict__ feat,             // [n_streams][PN_FEAT_STRIDE]
     int *__restrict__ silence,            // [n_streams]
-    int *__restrict__ last_period, float *__restrict__ last_gain) {
+    int *__restrict__ last_period, float *__restrict__ last_gain,
+    float *__restrict__ aux) {            // optional [n_streams][PN_AUX_STRIDE]: Ep[34] | Exp[34] (un-scaled) | pitch_corr
   __shared__ FeShared SH;
   const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid >> 6;
   const int sub = lane / L, l = lane % L, gb = sub * L;
@@ -396,10 +398,11 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       for (int i4 = l; i4 < PN_FRAME / 4; i4 += L) {
         float4 v;
         if (sizeof(TIn) == 2) {
-          const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * PN_FRAME + 4 * i4);
-          v = make_float4(((float)q.x) / 32768.f, ((float)q.y) / 32768.f, ((float)q.z) / 32768.f, ((float)q.w) / 32768.f);  // main.cpp:34
+          const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * in_stride + 4 * i4);
+          // a power-of-two scale: the product is exact, == the reference's division (main.cpp:34)
+          v = make_float4(((float)q.x) * i16_scale, ((float)q.y) * i16_scale, ((float)q.z) * i16_scale, ((float)q.w) * i16_scale);
         } else {
-          v = *reinterpret_cast<const float4 *>(in + (size_t)s * PN_FRAME + 4 * i4);
+          v = *reinterpret_cast<const float4 *>(in + (size_t)s * in_stride + 4 * i4);
         }
         *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = v;
       }
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
           Exp = (float)fmin(1.0, fmax(0.0, (double)Exp / sqrt(1e-15 + (double)(Ex * Ep[c]))));
           f[b] = W.e[1][b] * 30;              // create_features (487-496)
           f[PN_NB + b] = Exp * 30;
+          if (aux) { aux[(size_t)s * PN_AUX_STRIDE + b] = Ep[c]; aux[(size_t)s * PN_AUX_STRIDE + PN_NB + b] = Exp; }
         }
       }
       // silence = sum(Ex) < 0.1 (429-433): sequential sum
@@ -766,6 +770,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         silence[s] = ((double)E < 0.1) ? 1 : 0;
         f[68] = (float)pitch_index / (PN_PITCH_MAX - 3 * PN_PITCH_MIN);
         f[69] = pitch_corr;
+        if (aux) aux[(size_t)s * PN_AUX_STRIDE + 2 * PN_NB] = pitch_corr;
       }
       PN_WAVE_SYNC();
     }
@@ -774,17 +779,18 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
 
 // ---- launcher ---------------------------------------------------------------------------------
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
-                        int in_is_i16, float *hist, float2 *yring, float *eyring, float2 *Ps, float *feat,
-                        int *silence, int *last_period, float *last_gain) {
+                        int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
+                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
   const int need = (n_streams + FE_SPB - 1) / FE_SPB;
   const int grid = need < 256 ? need : 256;            // one 146 KB block per CU, grid-stride
   const int frame_t = (int)(frame % PN_HIST_FRAMES);
   const int slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
   if (in_is_i16)
     hipLaunchKernelGGL(pn_frontend_kernel<int16_t>, dim3(grid), dim3(FE_THREADS), 0, st, T, n_streams, frame_t,
-                       slot_w, slot_r, (const int16_t *)in, hist, yring, eyring, Ps, feat, silence, last_period,
-                       last_gain);
+                       slot_w, slot_r, (const int16_t *)in, in_stride, i16_scale, hist, yring, eyring, Ps, feat, silence,
+                       last_period, last_gain, aux);
   else
     hipLaunchKernelGGL(pn_frontend_kernel<float>, dim3(grid), dim3(FE_THREADS), 0, st, T, n_streams, frame_t, slot_w,
-                       slot_r, (const float *)in, hist, yring, eyring, Ps, feat, silence, last_period, last_gain);
+                       slot_r, (const float *)in, in_stride, i16_scale, hist, yring, eyring, Ps, feat, silence, last_period,
+                       last_gain, aux);
 }

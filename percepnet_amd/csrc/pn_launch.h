@@ -1,0 +1,33 @@
+// Kernel launchers shared by the host files (pn_context.cpp, pn_featgen.cpp).
+#pragma once
+#include "pn_common.h"
+
+// ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
+struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
+// in: stream s's 480 samples at in + s*in_stride; i16_scale: 1/32768 (CLI, main.cpp:34) or 1 (training binary,
+// denoise.cpp:41,697); aux: optional [n_streams][PN_AUX_STRIDE] side outputs for the training-feature path
+void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
+                        int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
+                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+// training-feature path (pn_targets.hip)
+void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
+                       const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,
+                       const int *period_noisy, float *records, long long rec_stride, float *gr);
+void pn_launch_saturate_i16(hipStream_t st, int n_pairs, const float *in, int16_t *out, long long out_stride);
+void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
+                       const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
+size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
+void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
+size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);
+void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);
+void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, int n_rows);
+void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, const float *h_old, const void *Wp, const void *Up,
+                       const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
+int pn_dense_nt(int N);
+void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows);
+void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
+                   const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
+                   float *h_new, int n_rows);
+

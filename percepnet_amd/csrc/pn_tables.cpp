@@ -46,6 +46,9 @@ void pn_build_tables(PnTables *t) {
       temp_sum += t->comb_hann[i - 1];
     }
     for (int i = 1; i < PN_COMB_M * 2 + 2; i++) t->comb_hann[i - 1] /= temp_sum;
+    t->pna = 0;                                             // denoise.cpp:207-210 (float accumulation)
+    for (int i = 1; i < PN_COMB_M * 2 + 2; i++) t->pna += t->comb_hann[i - 1] * t->comb_hann[i - 1];
+    t->n0 = 0.03;                                           // denoise.cpp:211
   }
   {
     const int N = PN_NB - 2;

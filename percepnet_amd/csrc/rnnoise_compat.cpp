@@ -125,3 +125,24 @@ float rnnoise_process_frame_c(DenoiseState *st, float *out, const float *in, FIL
 RNNModel *rnnoise_model_from_file_c(FILE *f) { return rnnoise_model_from_file(f); }
 void rnnoise_model_free_c(RNNModel *m) { rnnoise_model_free(m); }
 }
+
+// ---- train(), rnnoise.h:66 / denoise.cpp:603-787: the body of the `percepNet` binary -----------------
+// Same argv contract (<speech> <noisy> <count> <output>) and the same by-products in the cwd
+// (test_output.pcm, test_input.pcm); one job = a batch of one pair — for dataset-scale runs use
+// pn_featgen_run_files / the percepnet_featgen CLI with many jobs per call.
+int train(int argc, char **argv) {
+  if (argc != 5) {
+    fprintf(stderr, "usage: %s <speech> <noisy> <count> <output>\n", argv[0]);
+    return 1;
+  }
+  int dev = 0;
+  if (const char *d = getenv("PERCEPNET_DEVICE")) dev = atoi(d);
+  const char *sp = argv[1], *no = argv[2], *out = argv[4], *to = "test_output.pcm", *ti = "test_input.pcm";
+  const int count = atoi(argv[3]);
+  if (pn_featgen_run_files(dev, 1, &sp, &no, &count, &out, &to, &ti)) {
+    fprintf(stderr, "percepnet_hip train: %s\n", pn_last_error());
+    return 1;
+  }
+  return 0;
+}
+extern "C" int rnnoise_train_c(int argc, char **argv) { return train(argc, argv); }

@@ -78,3 +78,28 @@ def synth_batch_fast(n_streams, n_frames, seed=0):
         lo, hi = r * pool.shape[0], min((r + 1) * pool.shape[0], n_streams)
         out[lo:hi] = np.roll(out[lo:hi], 37 * r, axis=1)
     return out
+
+
+def synth_pair(p, n_frames, base_seed=BASE_SEED):
+    """-> (speech, noisy) int16[n_frames*480] for training-feature pair ``p``: the speech file is
+    synth_stream(p); the noisy file is that speech plus white noise (SNR varies with p) plus a
+    quieter interfering stream.  Every 4th pair has 12 frames of digital silence in both files (at
+    NORM_RATIO 1 only exact zeros reach train()'s `silence` branch, denoise.cpp:433,744)."""
+    speech = synth_stream(p, n_frames, base_seed).astype(np.int32)
+    rng = np.random.default_rng(base_seed + 100003 + p)
+    sigma = 10.0 ** rng.uniform(1.5, 3.3)
+    noise = rng.standard_normal(n_frames * FRAME) * sigma
+    interf = synth_stream(p + 1000, n_frames, base_seed).astype(np.int32) // 4
+    noisy = speech + np.rint(noise).astype(np.int32) + interf
+    if p % 4 == 3 and n_frames > 24:
+        speech[8 * FRAME:20 * FRAME] = 0
+        noisy[8 * FRAME:20 * FRAME] = 0
+    return (np.clip(speech, -32768, 32767).astype(np.int16), np.clip(noisy, -32768, 32767).astype(np.int16))
+
+
+def synth_pairs(n_pairs, n_frames, base_seed=BASE_SEED):
+    sp = np.empty((n_pairs, n_frames * FRAME), np.int16)
+    no = np.empty((n_pairs, n_frames * FRAME), np.int16)
+    for p in range(n_pairs):
+        sp[p], no[p] = synth_pair(p, n_frames, base_seed)
+    return sp, no

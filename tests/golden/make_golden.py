@@ -16,6 +16,10 @@ Produces
                           (percepNet_run semantics) for streams 0 (voiced), 3 (loud: non-silent
                           frames), 7 (bursts+silence), 13 (two-tone), 48 frames each, plus
                           float-in/float-out of stream 0 and of stream 3 at 4x scale.
+  featgen_golden.npz      (`make_golden.py featgen`) the compiled reference's train() — the `percepNet`
+                          training-feature binary, denoise.cpp:603-787 — run through real files on
+                          synthetic pairs 0, 2 and 3 (3 holds digital silence), 36 frames each:
+                          speech/noisy int16 in, the 138-float records and test_output.pcm out.
 """
 import ctypes
 import hashlib
@@ -111,5 +115,23 @@ def main():
     print("golden written")
 
 
+def make_featgen_golden():
+    from oracle.oracle import Reference
+    from percepnet_amd import synth
+    ref = Reference(None)
+    g = {}
+    for p in (0, 2, 3):
+        sp, no = synth.synth_pair(p, 36)
+        with tempfile.TemporaryDirectory() as d:
+            rec, pcm = ref.train(sp, no, d)
+        g[f"speech_{p}"] = sp; g[f"noisy_{p}"] = no; g[f"rec_{p}"] = rec; g[f"pcm_{p}"] = pcm
+    np.savez_compressed(os.path.join(HERE, "featgen_golden.npz"), **g)
+    print("featgen golden written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "featgen":
+        make_featgen_golden()
+    else:
+        main()
+        make_featgen_golden()

@@ -31,7 +31,8 @@ def test_reference_mangled_symbols_exported(lib):
     for n in ["_Z16rnnoise_get_sizev", "_Z12rnnoise_initP12DenoiseStateP8RNNModel",
               "_Z14rnnoise_createP8RNNModel", "_Z15rnnoise_destroyP12DenoiseState",
               "_Z21rnnoise_process_frameP12DenoiseStatePfPKfP8_IO_FILE",
-              "_Z23rnnoise_model_from_fileP8_IO_FILE", "_Z18rnnoise_model_freeP8RNNModel"]:
+              "_Z23rnnoise_model_from_fileP8_IO_FILE", "_Z18rnnoise_model_freeP8RNNModel",
+              "_Z5trainiPPc"]:          # int train(int, char**), rnnoise.h:66
         assert hasattr(lib, n), n
 
 
@@ -48,4 +49,6 @@ def test_model_parsing_and_error_paths_without_gpu(lib, blob):
         # the product path must fail loudly without a GPU — never fall back to a CPU path
         with pytest.raises(api.PercepNetError):
             api.Context(m, 4)
+        with pytest.raises(api.PercepNetError):
+            api.FeatGen(4)
     m.close()

@@ -124,3 +124,33 @@ def test_oracle_stages_vs_compiled_reference(blob, oracle):
     a, ga = o2.run_pcm(pcm); b, gb = r2.run_pcm(pcm)
     assert np.array_equal(a, b) and np.array_equal(ga.view(np.uint32), gb.view(np.uint32))
     assert ga.min() < 0.02 and ga.max() > 0.98
+
+
+# ---- the training-feature binary (train(), denoise.cpp:603-787) -------------------
+def test_train_oracle_matches_golden_records(oracle, golden_dir):
+    """Golden = the compiled reference's train() run through real files (make_golden.py featgen)."""
+    g = np.load(os.path.join(golden_dir, "featgen_golden.npz"))
+    for p in (0, 2, 3):
+        sp, no = synth.synth_pair(p, 36)
+        assert np.array_equal(sp, g[f"speech_{p}"]) and np.array_equal(no, g[f"noisy_{p}"])   # generator did not drift
+        rec, pcm = oracle.train_run(sp, no)
+        assert np.array_equal(rec.view(np.uint32), g[f"rec_{p}"].view(np.uint32)), p
+        assert np.array_equal(pcm, g[f"pcm_{p}"]), p
+    r3 = g["rec_3"]
+    assert (r3[14:25, 70:104] == 0).all()             # window of frame t = input frames t-6, t-5: all-zero for t in [14, 24]
+    assert np.isfinite(r3).all()
+    assert (g["rec_0"][:, 104:] == np.float32(0.99)).any()      # adjust_gain_strength_by_condition branch taken
+
+
+@pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no /root/reference)")
+def test_train_oracle_bit_exact_vs_compiled_reference(blob, oracle, tmp_path):
+    ref = Reference(blob)
+    for p in (1, 5, 7):
+        sp, no = synth.synth_pair(p, 50)
+        d = tmp_path / f"p{p}"; d.mkdir()
+        rr, rp = ref.train(sp, no, str(d))
+        orc, op = oracle.train_run(sp, no)
+        assert np.array_equal(rr.view(np.uint32), orc.view(np.uint32)), p
+        assert np.array_equal(rp, op), p
+        # the reference's other by-product: test_input.pcm == the noisy input
+        assert np.array_equal(np.fromfile(d / "test_input.pcm", np.int16), no)
