@@ -38,14 +38,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name, defines, verbose=False):
+def build_variant(name, defines, verbose=False, only=None):
     """Tuning aid: build lib/variants/<name>/libpercepnet_hip.so with extra -D flags
-    (select it at run time with PERCEPNET_LIB=<path>)."""
+    (select it at run time with PERCEPNET_LIB=<path>).  only: sources to recompile with the flags;
+    the other objects are taken from the default build."""
     vdir = os.path.join(LIBDIR, "variants", name)
     os.makedirs(vdir, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o"))
+            continue
         o = os.path.join(vdir, src.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc] + FLAGS + list(defines) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
               ["-c", os.path.join(CSRC, src), "-o", o]

@@ -285,12 +285,15 @@ __device__ __forceinline__ void fe_chain2(const float *a, const float *b1, const
 #undef FE_CH2_MAC
 
 // find_best_pitch (pitch.cpp:46-104, float instantiation).  Group-uniform recurrence on broadcast
-// operands: the squares y[j]^2 (64 at a time into sq) and the window updates
-// d[i] = y[i+LEN]^2 - y[i]^2 are formed lane-parallel first (same roundings), so the serial loops
-// are one add (resp. add + max + compare) per step.  xcorr, d, sq 16-byte aligned.
+// operands.  Everything that is not order-dependent is formed lane-parallel first with the reference's
+// roundings: the squares y[j]^2 for the initial energy (64 at a time into sq), the window updates
+// d[i] = y[i+LEN]^2 - y[i]^2, and the numerators num[i] = (xcorr[i]*1e-12)^2, with NaN standing for
+// "xcorr[i] <= 0: candidate skipped" (every comparison against NaN is false).  The serial scan is then
+// branch-free: two cross-multiplied comparisons and selects on the (best, second best) state, plus
+// the running-energy add + clamp, per candidate.  xcorr, d, sq 16-byte aligned; sq holds 64 floats.
 template <int LEN, int MAXP>
 __device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const float *y, float *sq, float *d, int l,
-                                                   int &bp0, int &bp1) {
+                                                   int &bp0_out, int &bp1_out) {
   constexpr int MP4 = (MAXP + 3) & ~3;
   for (int i = l; i < MP4; i += L) {
     const int ic = i < MAXP ? i : MAXP - 1;
@@ -315,40 +318,62 @@ __device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const flo
       }
     }
   }
-  PN_WAVE_SYNC();
   float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-  bp0 = 0; bp1 = 1;
-#define FE_FBP_STEP(xc_, dd_, idx_)                                                                  \
-  if ((idx_) < MAXP) {                                                                              \
-    if ((xc_) > 0) {                                                                                \
-      float x16 = (xc_);                                                                            \
-      x16 *= 1e-12f;                                                                                \
-      const float num = x16 * x16;                                                                  \
-      if (num * bd1 > bn1 * Syy) {                                                                  \
-        if (num * bd0 > bn0 * Syy) { bn1 = bn0; bd1 = bd0; bp1 = bp0; bn0 = num; bd0 = Syy; bp0 = (idx_); } \
-        else { bn1 = num; bd1 = Syy; bp1 = (idx_); }                                                \
-      }                                                                                             \
-    }                                                                                               \
+  int bp0 = 0, bp1 = 1;
+#define FE_FBP_STEP(nm_, dd_, idx_) do {                                                            \
+    const float num = (nm_);                                                                        \
+    const bool c1 = num * bd1 > bn1 * Syy;                                                          \
+    const bool c0 = c1 && (num * bd0 > bn0 * Syy);                                                  \
+    bn1 = c0 ? bn0 : (c1 ? num : bn1); bd1 = c0 ? bd0 : (c1 ? Syy : bd1); bp1 = c0 ? bp0 : (c1 ? (idx_) : bp1); \
+    bn0 = c0 ? num : bn0; bd0 = c0 ? Syy : bd0; bp0 = c0 ? (idx_) : bp0;                            \
     Syy += (dd_);                                                                                   \
     Syy = (1 > Syy) ? 1 : Syy;                                                                      \
-  }
+  } while (0)
 #pragma unroll 1
-  for (int i0 = 0; i0 < MAXP; i0 += 16) {
-    float4 xv[4], dv[4];
+  for (int blk = 0; blk < (MAXP + 63) / 64; blk++) {
+    float nv[64 / L];
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int i = (i0 + 4 * v < MP4) ? i0 + 4 * v : 0;
-      xv[v] = *reinterpret_cast<const float4 *>(xcorr + i);
-      dv[v] = *reinterpret_cast<const float4 *>(d + i);
+    for (int w = 0; w < 64 / L; w++) {
+      const int i = 64 * blk + l + L * w;
+      const float xc = xcorr[i < MAXP ? i : 0];
+      float x16 = xc;
+      x16 *= 1e-12f;
+      nv[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");
     }
+    PN_WAVE_SYNC();
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      FE_FBP_STEP(xv[v].x, dv[v].x, i0 + 4 * v) FE_FBP_STEP(xv[v].y, dv[v].y, i0 + 4 * v + 1)
-      FE_FBP_STEP(xv[v].z, dv[v].z, i0 + 4 * v + 2) FE_FBP_STEP(xv[v].w, dv[v].w, i0 + 4 * v + 3)
+    for (int w = 0; w < 64 / L; w++) sq[l + L * w] = nv[w];
+    PN_WAVE_SYNC();
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int i = 64 * blk + 4 * v;
+      if (i < MAXP) {
+        const float4 n4 = *reinterpret_cast<const float4 *>(sq + 4 * v);
+        const float4 d4 = *reinterpret_cast<const float4 *>(d + i);
+        FE_FBP_STEP(n4.x, d4.x, i); FE_FBP_STEP(n4.y, d4.y, i + 1);
+        FE_FBP_STEP(n4.z, d4.z, i + 2); FE_FBP_STEP(n4.w, d4.w, i + 3);
+      }
     }
   }
 #undef FE_FBP_STEP
+  bp0_out = bp0; bp1_out = bp1;
 }
+
+// Tuning aid (variant builds with -DPN_FE_CLOCKS only): wave 0 of every block accumulates the shader-clock
+// cycles between phase marks into pn_fe_clk[]; read back with pn_fe_clocks_read().
+#ifdef PN_FE_CLOCKS
+#define FE_NMARK 24
+__device__ unsigned long long pn_fe_clk[FE_NMARK];
+#define FE_MARK(i) do { const long long now_ = __builtin_readcyclecounter(); \
+    if (tid == 0) atomicAdd(&pn_fe_clk[i], (unsigned long long)(now_ - tmark_)); tmark_ = __builtin_readcyclecounter(); } while (0)
+extern "C" int pn_fe_clocks_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_fe_clk), sizeof(unsigned long long) * FE_NMARK) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[FE_NMARK] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pn_fe_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return FE_NMARK;
+}
+#else
+#define FE_MARK(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
 
@@ -391,6 +416,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
 
   for (int s0 = (blockIdx.x * FE_WPB + wave) * G; s0 < n_streams; s0 += gridDim.x * FE_SPB) {
     const int s = s0 + sub;
+#ifdef PN_FE_CLOCKS
+    long long tmark_ = __builtin_readcyclecounter();
+#endif
     if (s < n_streams) {
       float *h = hist + (size_t)s * PN_HIST;
       // -- history: the shift+append of denoise.cpp:388-389 becomes one ring-slot write ---------
@@ -407,6 +435,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = v;
       }
       PN_WAVE_SYNC_GLOBAL();
+      FE_MARK(0);
       // -- Y = FFT(window(newest 960 samples)), Ey (compute_lookahead_band_energy 498-506); kept in
       //    the ring: it is X / Ex of frame t+5 (frame_analysis 333-346) --------------------------------
       {
@@ -430,7 +459,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
           }
         }
       }
+      FE_MARK(1);   // window + scatter
       fe_fft960(W.fft, S.tw, l);
+      FE_MARK(2);   // look-ahead FFT
       {
         float2 *yw = yring + ((size_t)slot_w * n_streams + s) * PN_SPEC_BINS;
         for (int k = l; k < PN_SPEC_BINS; k += L) yw[k] = W.fft[k];
@@ -446,6 +477,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       const float *Exr = eyring + ((size_t)slot_r * n_streams + s) * 36;            // Ex(t) = Ey(t-5)
       for (int b = l; b < PN_NB; b += L) W.e[0][b] = Exr[b];
       PN_WAVE_SYNC();
+      FE_MARK(3);
 
 #if defined(PN_FE_ABL) && PN_FE_ABL == 1
       continue;   // timing ablation (tools/kernel_times.py): history write + look-ahead FFT + band energies only
@@ -472,6 +504,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         }
       }
       PN_WAVE_SYNC();
+      FE_MARK(4);   // downsample
       // _celt_autocorr (celt_lpc.cpp:198-279): lane k holds lag k (lanes > 4 shadow lag 4)
       float ac[5];
       {
@@ -524,6 +557,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         lpc2[3] = lpc[3] + .8f * lpc[2];
         lpc2[4] = .8f * lpc[3];
       }
+      FE_MARK(5);   // autocorr + LPC
       // celt_fir5 (pitch.cpp:106-145): out of place, raw -> pbuf
 #pragma unroll 2
       for (int i = l; i < 864; i += L) {
@@ -537,6 +571,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       }
       PN_WAVE_SYNC();
 
+      FE_MARK(6);   // FIR
 #if defined(PN_FE_ABL) && PN_FE_ABL == 2
       continue;   // timing ablation: + downsample, autocorr, LPC, FIR
 #endif
@@ -546,34 +581,48 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       for (int j = l; j < 387; j += L) y4[j] = pbuf[2 * j];
       PN_WAVE_SYNC();
       {
+        // two register sets of 8 steps each: the LDS reads of the next 8 steps are in flight while the
+        // (per-lag serially dependent) adds of the current 8 execute
         float sacc[NCH];
+        int lagc[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) sacc[c] = 0;
-        const int lmax = 146;
+        for (int c = 0; c < NCH; c++) { sacc[c] = 0; lagc[c] = (l + L * c <= 146) ? l + L * c : 146; }
+#ifndef PN_FE_CXS
+#define PN_FE_CXS 4
+#endif
+        constexpr int CXS = PN_FE_CXS;                 // steps per register set (even, 240 % (2*CXS) == 0)
+        static_assert(CXS % 2 == 0 && 240 % (2 * CXS) == 0, "CXS");
+        float xa0[CXS], xa1[CXS], yb0[NCH][CXS], yb1[NCH][CXS];
+#define FE_CX_LOAD(xa, yb, j0) do {                                                                    \
+          _Pragma("unroll") for (int v_ = 0; v_ < CXS / 2; v_++) {                                         \
+            const float4 q_ = *reinterpret_cast<const float4 *>(pbuf + 384 + 2 * (j0) + 4 * v_);           \
+            (xa)[2 * v_] = q_.x; (xa)[2 * v_ + 1] = q_.z; }                                                \
+          _Pragma("unroll") for (int c_ = 0; c_ < NCH; c_++)                                               \
+            _Pragma("unroll") for (int u_ = 0; u_ < CXS; u_++) (yb)[c_][u_] = y4[lagc[c_] + (j0) + u_];    \
+        } while (0)
+#define FE_CX_MAC(xa, yb) do {                                                                         \
+          _Pragma("unroll") for (int u_ = 0; u_ < CXS; u_++)                                               \
+            _Pragma("unroll") for (int c_ = 0; c_ < NCH; c_++) sacc[c_] = sacc[c_] + (xa)[u_] * (yb)[c_][u_]; \
+        } while (0)
+        FE_CX_LOAD(xa0, yb0, 0);
 #pragma unroll 1
-        for (int j0 = 0; j0 < 240; j0 += 4) {
-          const float4 a01 = *reinterpret_cast<const float4 *>(pbuf + 384 + 2 * j0);
-          const float4 a23 = *reinterpret_cast<const float4 *>(pbuf + 384 + 2 * j0 + 4);
-          const float a[4] = {a01.x, a01.z, a23.x, a23.z};
-          float bv[NCH][4];
-#pragma unroll
-          for (int c = 0; c < NCH; c++) {
-            const int lag = (l + L * c <= lmax) ? l + L * c : lmax;
-#pragma unroll
-            for (int u = 0; u < 4; u++) bv[c][u] = y4[lag + j0 + u];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int c = 0; c < NCH; c++) sacc[c] = sacc[c] + a[u] * bv[c][u];
+        for (int j0 = 0; j0 < 240; j0 += 2 * CXS) {
+          FE_CX_LOAD(xa1, yb1, j0 + CXS);
+          FE_CX_MAC(xa0, yb0);
+          if (j0 + 2 * CXS < 240) FE_CX_LOAD(xa0, yb0, j0 + 2 * CXS);
+          FE_CX_MAC(xa1, yb1);
         }
+#undef FE_CX_LOAD
+#undef FE_CX_MAC
 #pragma unroll
         for (int c = 0; c < NCH; c++) if (l + L * c < 147) xcorr[l + L * c] = sacc[c];
       }
       PN_WAVE_SYNC();
+      FE_MARK(7);   // y4 copy + coarse xcorr
       int bp0, bp1;
       fe_find_best_pitch<240, 147>(xcorr, y4, sq64, d1, l, bp0, bp1);
       PN_WAVE_SYNC();
+      FE_MARK(8);   // find_best_pitch coarse
       // fine: only lags within +-2 of 2*best (pitch.cpp:344-361); other entries are 0
       for (int i = l; i < 296; i += L) xcorr[i] = 0;
       PN_WAVE_SYNC();
@@ -584,6 +633,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         if (act) xcorr[c] = (-1 > sum) ? -1 : sum;   // duplicates (overlapping windows) write the same value
       }
       PN_WAVE_SYNC();
+      FE_MARK(9);   // fine xcorr
       fe_find_best_pitch<480, 294>(xcorr, pbuf, sq64, y4, l, bp0, bp1);   // y_lp4 is dead: its space holds d[]
       int offset = 0;
       if (bp0 > 0 && bp0 < 294 - 1) {
@@ -595,6 +645,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       int pitch_index = PN_PITCH_MAX - (2 * bp0 - offset);       // denoise.cpp:408
       PN_WAVE_SYNC();
 
+      FE_MARK(10);  // find_best_pitch fine + interp
 #if defined(PN_FE_ABL) && PN_FE_ABL == 3
       continue;   // timing ablation: + pitch_search
 #endif
@@ -621,6 +672,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         fe_chain2<480>(x, x - lag1, x - lag2, dot1, dot2);
         const float xx = __shfl(dot1, gb);
         float xy = __shfl(dot1, gb + 1);
+        FE_MARK(11);  // remove_doubling: 2x14 dot chains
         // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, group-uniform.  Squares
         // formed lane-parallel, 64 at a time, into a broadcast scratch (the dead xcorr area); the
         // recurrence reads them 4 per ds_read_b128; lane 0 stores the clamped results 4 at a time.
@@ -655,6 +707,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
           }
         }
         PN_WAVE_SYNC();
+        FE_MARK(12);  // yy_lookup recurrence
         float yy = yyl[T0];
         float best_xy = xy, best_yy = yy;
         const float g0 = fe_pitch_gain(xy, xx, yy);
@@ -698,12 +751,16 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
       if (l == 0) { last_period[s] = pitch_index; last_gain[s] = pg; }
       PN_WAVE_SYNC();
 
+      FE_MARK(13);  // decisions + final 3 chains
 #if defined(PN_FE_ABL) && PN_FE_ABL == 4
       continue;   // timing ablation: + remove_doubling
 #endif
       // -- comb filter (denoise.cpp:416-422) + window + FFT -> P, Ep, Exp -------------------------
       {
-        constexpr int CH = (L == 16) ? 12 : 10;         // samples per lane per chunk: 84 / 70 loads in flight
+#ifndef PN_FE_COMB_CH
+#define PN_FE_COMB_CH ((L == 16) ? 12 : 10)
+#endif
+        constexpr int CH = PN_FE_COMB_CH;               // samples per lane per chunk: 7*CH loads in flight
         static_assert((PN_WINDOW / L) % CH == 0, "chunk");
 #pragma unroll 1
         for (int i0 = l; i0 < PN_WINDOW; i0 += L * CH) {
@@ -724,7 +781,9 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
           }
         }
       }
+      FE_MARK(14);  // comb filter + window + scatter
       fe_fft960(W.fft, S.tw, l);
+      FE_MARK(15);  // P FFT
       {
         constexpr int NK = PN_SPEC_BINS / L;            // 25 at L=16
         float2 xv[NK];
@@ -745,10 +804,12 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
           float tmp = X.x * P.x; tmp += X.y * P.y; prod[k] = tmp;
         }
       }
+      FE_MARK(16);  // Pspec store + X.P products
       float Ep[NBND];
 #pragma unroll
       for (int c = 0; c < NBND; c++) Ep[c] = fe_band<false>(S, W.fft, nullptr, l + L * c);
       PN_WAVE_SYNC();
+      FE_MARK(17);  // Ep bands
       float *f = feat + (size_t)s * PN_FEAT_STRIDE;
 #pragma unroll
       for (int c = 0; c < NBND; c++) {
@@ -773,6 +834,7 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
         if (aux) aux[(size_t)s * PN_AUX_STRIDE + 2 * PN_NB] = pitch_corr;
       }
       PN_WAVE_SYNC();
+      FE_MARK(18);  // Exp bands + features
     }
   }
 }
