@@ -35,6 +35,18 @@
 #else
 #define PN_STAGE_ST(x) x
 #endif
+// -DPN_EXP_HOTA / -DPN_EXP_HOTB: every K-tile re-reads K-tile 0 of the activations / weights (cache-hot operands:
+// separates the memory-system cost of the staging loads from their issue cost)
+#ifdef PN_EXP_HOTA
+#define PN_EXP_KA(k) ((k) & 0)
+#else
+#define PN_EXP_KA(k) (k)
+#endif
+#ifdef PN_EXP_HOTB
+#define PN_EXP_KB(k) ((k) & 0)
+#else
+#define PN_EXP_KB(k) (k)
+#endif
 #ifdef PN_EXP_NOBARRIER
 #define PN_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -309,10 +321,10 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
     const bool p1_ = g_ < T1;                                                                              \
     const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    pn_load_A((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old, p1_ ? pld : N, p1_ ? k0_ : kh_ * BK, m0); \
-    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)kx_ * 1024 : Uz + (size_t)kh_ * 1024);                         \
-    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)kx_ * 1024 : Ur + (size_t)kh_ * 1024);                         \
-    (R).b[2] = pn_load_B(p1_ ? Wh + (size_t)kx_ * 1024 : Uh + (size_t)kh_ * 1024);                         \
+    pn_load_A((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old, p1_ ? pld : N, PN_EXP_KA(p1_ ? k0_ : kh_ * BK), m0); \
+    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)PN_EXP_KB(kx_) * 1024 : Uz + (size_t)PN_EXP_KB(kh_) * 1024);   \
+    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)PN_EXP_KB(kx_) * 1024 : Ur + (size_t)PN_EXP_KB(kh_) * 1024);   \
+    (R).b[2] = pn_load_B(p1_ ? Wh + (size_t)PN_EXP_KB(kx_) * 1024 : Uh + (size_t)PN_EXP_KB(kh_) * 1024);   \
   } while (0)
   GRU_FETCH(R0, 0); GRU_FETCH(R1, 1);
   pn_tile_stash<3>(S.A[0], S.B[0], R0);
@@ -347,6 +359,182 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+#ifdef PN_EXP_NOEPI
+      if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh;
+#else
+      const float z = pn_sigmoid(acc[0][i], S.tansig);
+      const float r = pn_sigmoid(acc[1][i], S.tansig);
+      float h = bh;
+      h += acc[3][i] * r;
+      h = h + acc[2][i];
+      const float hv = pn_act(h, act, S.tansig);
+      if (row < n_rows) {
+        const float ho = h_old[(size_t)row * N + col];
+        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
+      }
+#endif
+    }
+  }
+#undef GRU_FETCH
+}
+
+// =============================== half-tile software pipeline ========================================
+// The K loop above leaves two kinds of bubbles per K-tile in every wave: the two batches of LDS operand
+// reads are waited for right before the MFMAs that use them, and the global prefetch / LDS stash /
+// barrier sit between MFMA blocks; two co-resident blocks run in lock-step, so the second wave of the
+// SIMD does not fill them (measured: operands hot in cache change nothing, removing the staging
+// instructions gains 17 %).  The kernels below issue every non-MFMA instruction in the shadow of an
+// MFMA: per K-tile g ("interval", between two block barriers)
+//     read half 0 of tile g from LDS            | interleaved with the MFMAs of half 1 of tile g-1
+//     global loads of tile g+2 -> registers     |   (one piece after each 3-MFMA k-step)
+//     read half 1 of tile g from LDS            | interleaved with the MFMAs of half 0 of tile g
+//     registers of tile g+1 -> the other buffer |
+//     barrier
+// LDS buffer discipline: tile g is written during interval g-1 and read only during interval g.
+// The order is pinned with sched_barrier(0) between pieces; numerics are unchanged (same MFMAs in the
+// same k order per accumulator).
+template <int NB> struct PnHalfOps { float4 a[2]; float4 b[NB][2]; };
+#define PN_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int NB, int HF, int QQ>
+__device__ __forceinline__ void pn_lds_read_q(PnHalfOps<NB> &o, const float (*As)[LDT], const float (*Bs)[LDT],
+                                              int wave, int lane) {
+  const int r = lane & 31, kh = lane >> 5;
+  constexpr int q = 2 * HF + QQ;
+  o.a[QQ] = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
+#pragma unroll
+  for (int t = 0; t < NB; t++) o.b[t][QQ] = *reinterpret_cast<const float4 *>(&Bs[32 * t + r][q * 8 + kh * 4]);
+}
+// one k-step (2 k values) of a GRU half tile: 3 MFMAs
+#define PN_G3(o, QQ, c, I0, I1, I2) do {                                                                   \
+    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[0][QQ].c, acc[I0], 0, 0, 0);         \
+    acc[I1] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[1][QQ].c, acc[I1], 0, 0, 0);         \
+    acc[I2] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[2][QQ].c, acc[I2], 0, 0, 0);         \
+    PN_SB(); } while (0)
+// one A-panel float4 of the staging set (piece `it` of pn_load_A / pn_store_A)
+__device__ __forceinline__ float4 pn_load_A1(const float *__restrict__ p, int ld, int k0, int m0, int it) {
+  const int idx = threadIdx.x + NN_THREADS * it;
+  return *reinterpret_cast<const float4 *>(p + (size_t)(m0 + (idx >> 3)) * ld + k0 + 4 * (idx & 7));
+}
+__device__ __forceinline__ void pn_store_A1(float (*As)[LDT], const float4 &v, int it) {
+  const int idx = threadIdx.x + NN_THREADS * it;
+  const int row = idx >> 3, c = idx & 7;
+  float *dst = &As[row][(c >> 1) * 8 + 2 * (c & 1)];
+  *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
+  *reinterpret_cast<float2 *>(dst + 4) = make_float2(v.y, v.w);
+}
+
+__global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
+    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
+    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
+    float *__restrict__ h_new, int n_rows, int n_mtiles) {
+  __shared__ NnShared S;
+  const int NTn = N >> 5;
+  int mt, nt;
+  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = mt * BM, KTh = N >> 5;
+  const int T1 = KTx, TT = KTx + KTh;
+  const int col = nt * 32 + (lane & 31);
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+
+  floatx16 acc[4];
+  {
+    float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
+    float br = b[N + col]; br += b[4 * N + col];// 147-153
+    const float bt = b[5 * N + col];            // 164
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
+  }
+  const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
+              *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
+  const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
+              *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
+  PN_PANEL_LOCALS(X);
+  PnTileRegs<3> R0, R1;
+  PnHalfOps<3> op0, op1;
+  // scalar operand selection for tile gg (clamped past the end: re-reads the last tile, never used)
+#define GP_SEL(gg)                                                                                        \
+    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
+    const bool p1_ = g_ < T1;                                                                              \
+    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
+    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
+    const float *ap_ = p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old;                                       \
+    const int ald_ = p1_ ? pld : N, ak_ = p1_ ? k0_ : kh_ * BK;                                            \
+    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
+    const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
+#define GP_FETCH_ALL(R, gg) do { GP_SEL(gg);                                                               \
+    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) (R).a[it_] = pn_load_A1(ap_, ald_, ak_, m0, it_);  \
+    (R).b[0] = pn_load_B(bz_); (R).b[1] = pn_load_B(br_); (R).b[2] = pn_load_B(bh_); } while (0)
+  // One interval.  RF: register set that receives tile g+2; RS: register set holding tile g+1 (stashed into
+  // buffer BUF^1).  PI2 / CI2: third accumulator of the previous / current tile (2 = hx for x tiles, 3 = tmp for h).
+#define GP_INTERVAL(gg, BUF, RF, RS, PI2, CI2, HAVE_PREV) do {                                             \
+    GP_SEL((gg) + 2);                                                                                      \
+    PN_SB();                                                                                               \
+    pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    if (HAVE_PREV) PN_G3(op1, 0, x, 0, 1, PI2);                                                            \
+    pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    if (HAVE_PREV) PN_G3(op1, 0, y, 0, 1, PI2);                                                            \
+    (RF).a[0] = pn_load_A1(ap_, ald_, ak_, m0, 0); PN_SB();                                                \
+    if (HAVE_PREV) PN_G3(op1, 0, z, 0, 1, PI2);                                                            \
+    (RF).a[1] = pn_load_A1(ap_, ald_, ak_, m0, 1); PN_SB();                                                \
+    if (HAVE_PREV) PN_G3(op1, 0, w, 0, 1, PI2);                                                            \
+    (RF).a[2] = pn_load_A1(ap_, ald_, ak_, m0, 2); PN_SB();                                                \
+    if (HAVE_PREV) PN_G3(op1, 1, x, 0, 1, PI2);                                                            \
+    (RF).a[3] = pn_load_A1(ap_, ald_, ak_, m0, 3); PN_SB();                                                \
+    if (HAVE_PREV) PN_G3(op1, 1, y, 0, 1, PI2);                                                            \
+    (RF).b[0] = pn_load_B(bz_); (RF).b[1] = pn_load_B(br_); PN_SB();                                       \
+    if (HAVE_PREV) PN_G3(op1, 1, z, 0, 1, PI2);                                                            \
+    (RF).b[2] = pn_load_B(bh_); PN_SB();                                                                   \
+    if (HAVE_PREV) PN_G3(op1, 1, w, 0, 1, PI2);                                                            \
+    PN_G3(op0, 0, x, 0, 1, CI2);                                                                           \
+    pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_G3(op0, 0, y, 0, 1, CI2);                                                                           \
+    pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_G3(op0, 0, z, 0, 1, CI2);                                                                           \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1); PN_SB();         \
+    PN_G3(op0, 0, w, 0, 1, CI2);                                                                           \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3); PN_SB();         \
+    PN_G3(op0, 1, x, 0, 1, CI2);                                                                           \
+    pn_store_B(&S.B[(BUF) ^ 1][0], (RS).b[0]); pn_store_B(&S.B[(BUF) ^ 1][32], (RS).b[1]); PN_SB();        \
+    PN_G3(op0, 1, y, 0, 1, CI2);                                                                           \
+    pn_store_B(&S.B[(BUF) ^ 1][64], (RS).b[2]); PN_SB();                                                   \
+    PN_G3(op0, 1, z, 0, 1, CI2);                                                                           \
+    PN_G3(op0, 1, w, 0, 1, CI2);                                                                           \
+    pn_mfma_drain();                                                                                       \
+    __syncthreads();                                                                                       \
+  } while (0)
+
+  GP_FETCH_ALL(R0, 0); GP_FETCH_ALL(R1, 1);
+  pn_tile_stash<3>(S.A[0], S.B[0], R0);
+  __syncthreads();
+  // tile g lives in LDS buffer g&1 and, before that, in register set R(g&1)
+  GP_INTERVAL(0, 0, R0, R1, 2, 2, false);
+#pragma unroll 1
+  for (int g = 1; g + 1 < T1; g += 2) {
+    GP_INTERVAL(g, 1, R1, R0, 2, 2, true);
+    GP_INTERVAL(g + 1, 0, R0, R1, 2, 2, true);
+  }
+  GP_INTERVAL(T1 - 1, 1, R1, R0, 2, 2, true);      // last x tile (T1 even)
+  GP_INTERVAL(T1, 0, R0, R1, 2, 3, true);          // first h tile; its first half still runs the x tile's MFMAs
+#pragma unroll 1
+  for (int g = T1 + 1; g + 1 < TT; g += 2) {
+    GP_INTERVAL(g, 1, R1, R0, 3, 3, true);
+    GP_INTERVAL(g + 1, 0, R0, R1, 3, 3, true);
+  }
+  GP_INTERVAL(TT - 1, 1, R1, R0, 3, 3, true);
+  PN_G3(op1, 0, x, 0, 1, 3); PN_G3(op1, 0, y, 0, 1, 3); PN_G3(op1, 0, z, 0, 1, 3); PN_G3(op1, 0, w, 0, 1, 3);
+  PN_G3(op1, 1, x, 0, 1, 3); PN_G3(op1, 1, y, 0, 1, 3); PN_G3(op1, 1, z, 0, 1, 3); PN_G3(op1, 1, w, 0, 1, 3);
+  pn_mfma_drain();
+#undef GP_INTERVAL
+#undef GP_FETCH_ALL
+#undef GP_SEL
+  // gates, candidate, blend (nnet.cpp:144,156,161-179)
+  {
+    const float bh = b[2 * N + col];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
       const float z = pn_sigmoid(acc[0][i], S.tansig);
       const float r = pn_sigmoid(acc[1][i], S.tansig);
       float h = bh;
@@ -359,7 +547,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
       }
     }
   }
-#undef GRU_FETCH
 }
 
 // ---- large-batch GRU tile: 256 streams x 64 neurons per block (8 waves) ----------------------------
@@ -605,6 +792,11 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
 #endif
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
+#ifdef PN_NN_OLD_PIPE
   hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
+#else
+  hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+                     tansig, h_new, n_rows, n_mtiles);
+#endif
 }
