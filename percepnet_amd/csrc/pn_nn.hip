@@ -394,6 +394,27 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
 // The order is pinned with sched_barrier(0) between pieces; numerics are unchanged (same MFMAs in the
 // same k order per accumulator).
 template <int NB> struct PnHalfOps { float4 a[2]; float4 b[NB][2]; };
+// timing experiments (results become wrong): drop the LDS operand reads / global prefetch loads / LDS stash of the K loop
+#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NORD)
+#define PN_PIECE_RD(...) do {} while (0);
+#else
+#define PN_PIECE_RD(...) __VA_ARGS__
+#endif
+#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NOLD) || defined(PN_EXP_CLUMP)
+#define PN_PIECE_LD(...) do {} while (0);
+#else
+#define PN_PIECE_LD(...) __VA_ARGS__
+#endif
+#ifdef PN_EXP_CLUMP          // all prefetch loads of an interval back-to-back right after the barrier
+#define PN_CLUMP_LD(...) __VA_ARGS__
+#else
+#define PN_CLUMP_LD(...) do {} while (0);
+#endif
+#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NOST)
+#define PN_PIECE_ST(...) do {} while (0);
+#else
+#define PN_PIECE_ST(...) __VA_ARGS__
+#endif
 #define PN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int NB, int HF, int QQ>
@@ -416,6 +437,16 @@ __device__ __forceinline__ float4 pn_load_A1(const float *__restrict__ p, int ld
   const int idx = threadIdx.x + NN_THREADS * it;
   return *reinterpret_cast<const float4 *>(p + (size_t)(m0 + (idx >> 3)) * ld + k0 + 4 * (idx & 7));
 }
+// uniform (SGPR) base + 32-bit per-lane byte offset: hipcc emits `global_load_dwordx4 v, v_off, s[base:base+1]`, no
+// 64-bit VALU address arithmetic in the K loop (the K-tile advance lives in the scalar base)
+__device__ __forceinline__ float4 pn_load_so(const float *__restrict__ ubase, unsigned off_bytes) {
+#ifdef PN_EXP_LD1           // timing experiment: one dword per load instead of four (same instruction count)
+  const float v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + off_bytes);
+  return make_float4(v, v, v, v);
+#else
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ubase) + off_bytes);
+#endif
+}
 __device__ __forceinline__ void pn_store_A1(float (*As)[LDT], const float4 &v, int it) {
   const int idx = threadIdx.x + NN_THREADS * it;
   const int row = idx >> 3, c = idx & 7;
@@ -423,6 +454,21 @@ __device__ __forceinline__ void pn_store_A1(float (*As)[LDT], const float4 &v, i
   *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.z);
   *reinterpret_cast<float2 *>(dst + 4) = make_float2(v.y, v.w);
 }
+
+// Tuning aid (-DPN_NN_CLOCKS): per-block shader-clock (s_memtime) and constant 100 MHz (s_memrealtime) ticks of the
+// pipelined GRU kernel, summed over blocks -> effective shader clock under this load, cycles per block.
+#ifdef PN_NN_CLOCKS
+__device__ unsigned long long pn_nn_clk[4];
+__device__ unsigned long long pn_nn_trace[8192 * 4];     // per block of the last N=512 launch: start, end (100 MHz ticks), HW_ID, XCC_ID
+extern "C" int pn_nn_trace_read(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_nn_trace), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -1;
+}
+extern "C" int pn_nn_clocks_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_nn_clk), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pn_nn_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 4;
+}
+#endif
 
 __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
@@ -432,6 +478,10 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
   const int NTn = N >> 5;
   int mt, nt;
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
+  pn_block_skew();
+#ifdef PN_NN_CLOCKS
+  const long long c0_ = __builtin_readcyclecounter(), r0_ = wall_clock64();
+#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = mt * BM, KTh = N >> 5;
   const int T1 = KTx, TT = KTx + KTh;
@@ -453,62 +503,77 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
   PN_PANEL_LOCALS(X);
   PnTileRegs<3> R0, R1;
   PnHalfOps<3> op0, op1;
+  // per-lane byte offsets of the four A float4 (x panels: row stride pld; h_old: row stride N) and of the B float4
+  unsigned aox[4], aoh[4];
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int idx = tid + NN_THREADS * it;
+    aox[it] = (unsigned)(((idx >> 3) * pld + 4 * (idx & 7)) * 4);
+    aoh[it] = (unsigned)(((idx >> 3) * N + 4 * (idx & 7)) * 4);
+  }
+  const unsigned bo4 = (unsigned)(tid * 16);
   // scalar operand selection for tile gg (clamped past the end: re-reads the last tile, never used)
 #define GP_SEL(gg)                                                                                        \
     int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
     const bool p1_ = g_ < T1;                                                                              \
     const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    const float *ap_ = p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old;                                       \
-    const int ald_ = p1_ ? pld : N, ak_ = p1_ ? k0_ : kh_ * BK;                                            \
-    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
+    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + PN_EXP_KA(k0_) : h_old + (size_t)m0 * N + PN_EXP_KA(kh_ * BK)); \
+    const size_t bo_ = (size_t)PN_EXP_KB(p1_ ? kx_ : kh_) * 1024;                                          \
     const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
+#define GP_LA(it) pn_load_so(ap_, p1_ ? aox[it] : aoh[it])
 #define GP_FETCH_ALL(R, gg) do { GP_SEL(gg);                                                               \
-    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) (R).a[it_] = pn_load_A1(ap_, ald_, ak_, m0, it_);  \
-    (R).b[0] = pn_load_B(bz_); (R).b[1] = pn_load_B(br_); (R).b[2] = pn_load_B(bh_); } while (0)
+    (R).a[0] = GP_LA(0); (R).a[1] = GP_LA(1); (R).a[2] = GP_LA(2); (R).a[3] = GP_LA(3);                    \
+    (R).b[0] = pn_load_so(bz_, bo4); (R).b[1] = pn_load_so(br_, bo4); (R).b[2] = pn_load_so(bh_, bo4); } while (0)
   // One interval.  RF: register set that receives tile g+2; RS: register set holding tile g+1 (stashed into
   // buffer BUF^1).  PI2 / CI2: third accumulator of the previous / current tile (2 = hx for x tiles, 3 = tmp for h).
 #define GP_INTERVAL(gg, BUF, RF, RS, PI2, CI2, HAVE_PREV) do {                                             \
     GP_SEL((gg) + 2);                                                                                      \
     PN_SB();                                                                                               \
-    pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_CLUMP_LD((RF).a[0] = GP_LA(0); (RF).a[1] = GP_LA(1); (RF).a[2] = GP_LA(2); (RF).a[3] = GP_LA(3);    \
+                (RF).b[0] = pn_load_so(bz_, bo4); (RF).b[1] = pn_load_so(br_, bo4); (RF).b[2] = pn_load_so(bh_, bo4);) PN_SB(); \
+    PN_PIECE_RD(pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
     if (HAVE_PREV) PN_G3(op1, 0, x, 0, 1, PI2);                                                            \
-    pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_PIECE_RD(pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
     if (HAVE_PREV) PN_G3(op1, 0, y, 0, 1, PI2);                                                            \
-    (RF).a[0] = pn_load_A1(ap_, ald_, ak_, m0, 0); PN_SB();                                                \
+    PN_PIECE_LD((RF).a[0] = GP_LA(0);) PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 0, z, 0, 1, PI2);                                                            \
-    (RF).a[1] = pn_load_A1(ap_, ald_, ak_, m0, 1); PN_SB();                                                \
+    PN_PIECE_LD((RF).a[1] = GP_LA(1);) PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 0, w, 0, 1, PI2);                                                            \
-    (RF).a[2] = pn_load_A1(ap_, ald_, ak_, m0, 2); PN_SB();                                                \
+    PN_PIECE_LD((RF).a[2] = GP_LA(2);) PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 1, x, 0, 1, PI2);                                                            \
-    (RF).a[3] = pn_load_A1(ap_, ald_, ak_, m0, 3); PN_SB();                                                \
+    PN_PIECE_LD((RF).a[3] = GP_LA(3);) PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 1, y, 0, 1, PI2);                                                            \
-    (RF).b[0] = pn_load_B(bz_); (RF).b[1] = pn_load_B(br_); PN_SB();                                       \
+    PN_PIECE_LD((RF).b[0] = pn_load_so(bz_, bo4); (RF).b[1] = pn_load_so(br_, bo4);) PN_SB();                             \
     if (HAVE_PREV) PN_G3(op1, 1, z, 0, 1, PI2);                                                            \
-    (RF).b[2] = pn_load_B(bh_); PN_SB();                                                                   \
+    PN_PIECE_LD((RF).b[2] = pn_load_so(bh_, bo4);) PN_SB();                                                         \
     if (HAVE_PREV) PN_G3(op1, 1, w, 0, 1, PI2);                                                            \
     PN_G3(op0, 0, x, 0, 1, CI2);                                                                           \
-    pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_PIECE_RD(pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
     PN_G3(op0, 0, y, 0, 1, CI2);                                                                           \
-    pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
+    PN_PIECE_RD(pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
     PN_G3(op0, 0, z, 0, 1, CI2);                                                                           \
-    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1); PN_SB();         \
+    PN_PIECE_ST(pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1);) PN_SB();\
     PN_G3(op0, 0, w, 0, 1, CI2);                                                                           \
-    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3); PN_SB();         \
+    PN_PIECE_ST(pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3);) PN_SB();\
     PN_G3(op0, 1, x, 0, 1, CI2);                                                                           \
-    pn_store_B(&S.B[(BUF) ^ 1][0], (RS).b[0]); pn_store_B(&S.B[(BUF) ^ 1][32], (RS).b[1]); PN_SB();        \
+    PN_PIECE_ST(pn_store_B(&S.B[(BUF) ^ 1][0], (RS).b[0]); pn_store_B(&S.B[(BUF) ^ 1][32], (RS).b[1]);) PN_SB();\
     PN_G3(op0, 1, y, 0, 1, CI2);                                                                           \
-    pn_store_B(&S.B[(BUF) ^ 1][64], (RS).b[2]); PN_SB();                                                   \
+    PN_PIECE_ST(pn_store_B(&S.B[(BUF) ^ 1][64], (RS).b[2]);) PN_SB();                                         \
     PN_G3(op0, 1, z, 0, 1, CI2);                                                                           \
     PN_G3(op0, 1, w, 0, 1, CI2);                                                                           \
     pn_mfma_drain();                                                                                       \
-    __syncthreads();                                                                                       \
+    PN_SYNC();                                                                                             \
   } while (0)
 
   GP_FETCH_ALL(R0, 0); GP_FETCH_ALL(R1, 1);
   pn_tile_stash<3>(S.A[0], S.B[0], R0);
   __syncthreads();
   // tile g lives in LDS buffer g&1 and, before that, in register set R(g&1)
+#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NORD)
+  pn_lds_read_q<3, 0, 0>(op0, S.A[0], S.B[0], wave, lane); pn_lds_read_q<3, 0, 1>(op0, S.A[0], S.B[0], wave, lane);
+  pn_lds_read_q<3, 1, 0>(op1, S.A[0], S.B[0], wave, lane); pn_lds_read_q<3, 1, 1>(op1, S.A[0], S.B[0], wave, lane);
+#endif
   GP_INTERVAL(0, 0, R0, R1, 2, 2, false);
 #pragma unroll 1
   for (int g = 1; g + 1 < T1; g += 2) {
@@ -528,13 +593,24 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
   pn_mfma_drain();
 #undef GP_INTERVAL
 #undef GP_FETCH_ALL
+#undef GP_LA
 #undef GP_SEL
+#ifdef PN_NN_CLOCKS
+  if (tid == 0) {
+    atomicAdd(&pn_nn_clk[0], (unsigned long long)(__builtin_readcyclecounter() - c0_));
+    atomicAdd(&pn_nn_clk[1], (unsigned long long)(wall_clock64() - r0_));
+    atomicAdd(&pn_nn_clk[2], 1ull);
+  }
+#endif
   // gates, candidate, blend (nnet.cpp:144,156,161-179)
   {
     const float bh = b[2 * N + col];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+#ifdef PN_EXP_NOEPI
+      if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh;
+#else
       const float z = pn_sigmoid(acc[0][i], S.tansig);
       const float r = pn_sigmoid(acc[1][i], S.tansig);
       float h = bh;
@@ -545,6 +621,116 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
         const float ho = h_old[(size_t)row * N + col];
         h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
       }
+#endif
+    }
+  }
+#ifdef PN_NN_CLOCKS
+  if (tid == 0 && N == 512 && blockIdx.x < 8192) {
+    unsigned long long *t = pn_nn_trace + (size_t)blockIdx.x * 4;
+    t[0] = (unsigned long long)r0_; t[1] = (unsigned long long)wall_clock64();
+    t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+}
+
+// Dense / conv-as-dense with the same half-tile pipeline (KT even, >= 2).
+#define PN_DN(o, QQ, c) do {                                                                               \
+    _Pragma("unroll") for (int t_ = 0; t_ < NT; t_++)                                                      \
+      acc[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[t_][QQ].c, acc[t_], 0, 0, 0);      \
+    PN_SB(); } while (0)
+template <int NT>
+__global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
+    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
+  __shared__ NnShared S;
+  int mt, cb;
+  if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
+  pn_block_skew();
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = mt * BM;
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int col = (cb * NT + t) * 32 + (lane & 31);
+    const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[t][i] = bv;
+  }
+  const float *wbase = Wp + (size_t)(cb * NT) * KT * 1024;
+  PN_PANEL_LOCALS(A);
+  PnTileRegs<NT> R0, R1;
+  PnHalfOps<NT> op0, op1;
+#define DP_SEL(gg)                                                                                         \
+    int g_ = (gg); g_ = g_ < KT ? g_ : KT - 1;                                                             \
+    const int sg_ = g_ / tps, ak_ = (g_ - sg_ * tps) * BK;                                                 \
+    const float *ap_ = pn_seg_ptr(PN_PANEL_PASS, sg_);                                                     \
+    const float *bp_ = wbase + (size_t)g_ * 1024
+#define DP_LOADB(R, t0, t1) do { _Pragma("unroll") for (int t_ = (t0); t_ < (t1); t_++)                    \
+      (R).b[t_] = pn_load_B(bp_ + (size_t)t_ * KT * 1024); } while (0)
+#define DP_STOREB(RS, BUF, t0, t1) do { _Pragma("unroll") for (int t_ = (t0); t_ < (t1); t_++)             \
+      pn_store_B(&S.B[(BUF) ^ 1][32 * t_], (RS).b[t_]); } while (0)
+#define DP_INTERVAL(gg, BUF, RF, RS, HAVE_PREV) do {                                                       \
+    DP_SEL((gg) + 2);                                                                                      \
+    PN_SB();                                                                                               \
+    pn_lds_read_q<NT, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                 \
+    if (HAVE_PREV) PN_DN(op1, 0, x);                                                                       \
+    pn_lds_read_q<NT, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                 \
+    if (HAVE_PREV) PN_DN(op1, 0, y);                                                                       \
+    (RF).a[0] = pn_load_A1(ap_, pld, ak_, m0, 0); PN_SB();                                                 \
+    if (HAVE_PREV) PN_DN(op1, 0, z);                                                                       \
+    (RF).a[1] = pn_load_A1(ap_, pld, ak_, m0, 1); PN_SB();                                                 \
+    if (HAVE_PREV) PN_DN(op1, 0, w);                                                                       \
+    (RF).a[2] = pn_load_A1(ap_, pld, ak_, m0, 2); PN_SB();                                                 \
+    if (HAVE_PREV) PN_DN(op1, 1, x);                                                                       \
+    (RF).a[3] = pn_load_A1(ap_, pld, ak_, m0, 3); PN_SB();                                                 \
+    if (HAVE_PREV) PN_DN(op1, 1, y);                                                                       \
+    DP_LOADB(RF, 0, NT / 2); PN_SB();                                                                      \
+    if (HAVE_PREV) PN_DN(op1, 1, z);                                                                       \
+    DP_LOADB(RF, NT / 2, NT); PN_SB();                                                                     \
+    if (HAVE_PREV) PN_DN(op1, 1, w);                                                                       \
+    PN_DN(op0, 0, x);                                                                                      \
+    pn_lds_read_q<NT, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                 \
+    PN_DN(op0, 0, y);                                                                                      \
+    pn_lds_read_q<NT, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                 \
+    PN_DN(op0, 0, z);                                                                                      \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1); PN_SB();         \
+    PN_DN(op0, 0, w);                                                                                      \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3); PN_SB();         \
+    PN_DN(op0, 1, x);                                                                                      \
+    DP_STOREB(RS, BUF, 0, NT / 2); PN_SB();                                                                \
+    PN_DN(op0, 1, y);                                                                                      \
+    DP_STOREB(RS, BUF, NT / 2, NT); PN_SB();                                                               \
+    PN_DN(op0, 1, z);                                                                                      \
+    PN_DN(op0, 1, w);                                                                                      \
+    pn_mfma_drain();                                                                                       \
+    PN_SYNC();                                                                                             \
+  } while (0)
+  pn_dense_fetch<NT>(R0, 0, KT, tps, PN_PANEL_PASS, wbase, m0);
+  pn_dense_fetch<NT>(R1, 1, KT, tps, PN_PANEL_PASS, wbase, m0);
+  pn_tile_stash<NT>(S.A[0], S.B[0], R0);
+  __syncthreads();
+  DP_INTERVAL(0, 0, R0, R1, false);
+#pragma unroll 1
+  for (int g = 1; g + 1 < KT; g += 2) {
+    DP_INTERVAL(g, 1, R1, R0, true);
+    DP_INTERVAL(g + 1, 0, R0, R1, true);
+  }
+  DP_INTERVAL(KT - 1, 1, R1, R0, true);
+  PN_DN(op1, 0, x); PN_DN(op1, 0, y); PN_DN(op1, 0, z); PN_DN(op1, 0, w);
+  PN_DN(op1, 1, x); PN_DN(op1, 1, y); PN_DN(op1, 1, z); PN_DN(op1, 1, w);
+  pn_mfma_drain();
+#undef DP_INTERVAL
+#undef DP_STOREB
+#undef DP_LOADB
+#undef DP_SEL
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int col = (cb * NT + t) * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (row < n_rows && col < N) out[(size_t)row * ldo + col] = pn_act(acc[t][i], act, S.tansig);
     }
   }
 }
@@ -764,6 +950,17 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
+#ifndef PN_NN_OLD_PIPE
+  if (KT >= 2 && KT % 2 == 0) {
+    if (NT == 4)
+      hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                         tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+    else
+      hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                         tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+    return;
+  }
+#endif
   if (NT == 4)
     hipLaunchKernelGGL(pn_dense_mfma_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);

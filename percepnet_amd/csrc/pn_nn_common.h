@@ -74,6 +74,24 @@ __device__ __forceinline__ void pn_mfma_drain() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// De-phase the two blocks that share a CU.  All blocks of a launch have the same length, so co-resident
+// blocks otherwise stay in lock-step for the whole launch and run their MFMA-free prologue (first tile
+// fetch) and epilogue (activations, state blend) at the same time, leaving the matrix pipe idle.  The
+// dispatcher hands out blocks round-robin over the 8 XCDs and fills every CU once before placing second
+// blocks, so blocks [256, 512) are the second residents of the first generation: delaying them once by
+// PN_BLOCK_SKEW x 8128 cycles keeps the pairs out of phase for all later generations as well.
+#ifndef PN_BLOCK_SKEW
+#define PN_BLOCK_SKEW 0
+#endif
+__device__ __forceinline__ void pn_block_skew() {
+#if PN_BLOCK_SKEW > 0
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll
+    for (int i = 0; i < PN_BLOCK_SKEW; i++) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+}
+
 // XCD-aware block numbering: hardware places block b on XCD b % 8; give each XCD whole
 // activation panels (all column tiles of an M tile run on the same XCD's L2).
 __device__ __forceinline__ bool pn_tile_of_block(int n_mtiles, int n_ctiles, int &mt, int &ct) {
