@@ -98,7 +98,7 @@ def pmc_traffic_bytes(streams):
     grid = f"grid={((streams + 127) // 128 + 7) // 8 * 8 * 16 * 256}"
     fetch = write = None
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith("pn_gru_mfma_kernel") and r["kernel"].endswith(grid):
+        if r["kernel"].startswith("pn_gru_mfma_p_kernel") and r["kernel"].endswith(grid):
             if r["counter"] == "FETCH_SIZE":
                 fetch = float(r["avg"]) * 1024 * 2
             elif r["counter"] == "WRITE_SIZE":
@@ -238,7 +238,7 @@ def main():
                 ach = flops / avg_s / 1e12
                 peak = 2500.0 if a.fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
                 res["roofline"] = {
-                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else "pn_gru_mfma_kernel") + " (512->512 reset-after GRU step, 4 launches per frame)",
+                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else "pn_gru_mfma_p_kernel") + " (512->512 reset-after GRU step, 4 launches per frame)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None if a.fp16 else traffic,
                     "traffic_source": traffic_src,
