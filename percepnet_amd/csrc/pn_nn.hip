@@ -633,6 +633,181 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
 #endif
 }
 
+// =============================== wave-specialised variant ========================================
+// Measured (profiles/README.md, tools/probes/mfma_vmem_probe.hip): a global load costs the wave that issues it
+// about 80 cycles of MFMA issue, while loads issued by ANOTHER wave of the same SIMD are free for it.  Here the
+// block has eight waves: waves 0-3 ("consumers", one 32-row strip each) only read LDS and issue MFMAs; waves
+// 4-7 ("producers") own the whole global -> register -> LDS stream of the block and nothing else.  Same LDS
+// discipline as the kernels above (tile g+1 is written during interval g and read during interval g+1), one
+// block barrier per interval shared by all eight waves, same numerics (same MFMAs, same k order).
+// Consumers read their operands one q-step (8 k values, 12 MFMAs) ahead instead of half a tile ahead: that
+// keeps the kernel at <= 128 registers, i.e. two 8-wave blocks per CU = 4 waves per SIMD, and 8-wave blocks
+// are placed symmetrically on the four SIMDs (a 6-wave variant at 3 waves/SIMD left slots empty for ~40 us
+// at every block turnover: profiles/README.md).
+#define WS_THREADS 512
+template <int NB> struct PnQOps { float4 a; float4 b[NB]; };
+template <int NB, int Q>
+__device__ __forceinline__ void pn_lds_read_1q(PnQOps<NB> &o, const float (*As)[LDT], const float (*Bs)[LDT],
+                                               int wave, int lane) {
+  const int r = lane & 31, kh = lane >> 5;
+  o.a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][Q * 8 + kh * 4]);
+#pragma unroll
+  for (int t = 0; t < NB; t++) o.b[t] = *reinterpret_cast<const float4 *>(&Bs[32 * t + r][Q * 8 + kh * 4]);
+}
+#define PN_Q3(o, c, I0, I1, I2) do {                                                                       \
+    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[0].c, acc[I0], 0, 0, 0);                 \
+    acc[I1] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[1].c, acc[I1], 0, 0, 0);                 \
+    acc[I2] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[2].c, acc[I2], 0, 0, 0);                 \
+    PN_SB(); } while (0)
+#define PN_Q3ALL(o, I0, I1, I2) do { PN_Q3(o, x, I0, I1, I2); PN_Q3(o, y, I0, I1, I2); PN_Q3(o, z, I0, I1, I2); \
+                                     PN_Q3(o, w, I0, I1, I2); } while (0)
+
+__global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
+    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
+    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
+    float *__restrict__ h_new, int n_rows, int n_mtiles) {
+  __shared__ NnShared S;
+  const int NTn = N >> 5;
+  int mt, nt;
+  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
+#ifdef PN_NN_CLOCKS
+  const long long r0_ = wall_clock64();
+#endif
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = mt * BM, KTh = N >> 5;
+  const int T1 = KTx, TT = KTx + KTh;
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+
+  if (wave >= 4) {
+    // ------------------------------------------------ producers ------------------------------------------
+    const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
+                *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
+    const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
+                *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
+    PN_PANEL_LOCALS(X);
+    const int ptid = tid - 256;
+    unsigned aox[4], aoh[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int idx = ptid + NN_THREADS * it;
+      aox[it] = (unsigned)(((idx >> 3) * pld + 4 * (idx & 7)) * 4);
+      aoh[it] = (unsigned)(((idx >> 3) * N + 4 * (idx & 7)) * 4);
+    }
+    const unsigned bo4 = (unsigned)(ptid * 16);
+    PnTileRegs<3> R0, R1;
+#define WS_SEL(gg)                                                                                        \
+    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
+    const bool p1_ = g_ < T1;                                                                              \
+    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
+    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
+    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + k0_ : h_old + (size_t)m0 * N + kh_ * BK); \
+    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
+    const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
+#define WS_FETCH(R, gg) do { WS_SEL(gg);                                                                   \
+    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) (R).a[it_] = pn_load_so(ap_, p1_ ? aox[it_] : aoh[it_]); \
+    (R).b[0] = pn_load_so(bz_, bo4); (R).b[1] = pn_load_so(br_, bo4); (R).b[2] = pn_load_so(bh_, bo4); } while (0)
+    // the stash helpers index by threadIdx.x & 255 == ptid for the producer half of the block
+#define WS_STASH(R, BUF) do {                                                                              \
+    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) {                                                  \
+      const int idx_ = ptid + NN_THREADS * it_; const int row_ = idx_ >> 3, c_ = idx_ & 7;                 \
+      float *dst_ = &S.A[BUF][row_][(c_ >> 1) * 8 + 2 * (c_ & 1)];                                         \
+      *reinterpret_cast<float2 *>(dst_) = make_float2((R).a[it_].x, (R).a[it_].z);                         \
+      *reinterpret_cast<float2 *>(dst_ + 4) = make_float2((R).a[it_].y, (R).a[it_].w); }                   \
+    _Pragma("unroll") for (int t_ = 0; t_ < 3; t_++)                                                       \
+      *reinterpret_cast<float4 *>(&S.B[BUF][32 * t_ + (ptid >> 3)][4 * (ptid & 7)]) = (R).b[t_]; } while (0)
+    WS_FETCH(R0, 0); WS_FETCH(R1, 1);
+    WS_STASH(R0, 0);
+    PN_SYNC();                                   // P_0: tile 0 visible
+    // interval g: fetch tile g+2 into the set tile g just left, stash tile g+1 into the other LDS buffer
+#pragma unroll 1
+    for (int g = 0; g < TT; g += 2) {
+      WS_FETCH(R0, g + 2); PN_SB();
+      WS_STASH(R1, 1);
+      PN_SYNC();
+      WS_FETCH(R1, g + 3); PN_SB();
+      WS_STASH(R0, 0);
+      PN_SYNC();
+    }
+#undef WS_STASH
+#undef WS_FETCH
+#undef WS_SEL
+    return;
+  }
+
+  // -------------------------------------------------- consumers ------------------------------------------
+#ifdef PN_WS_PRIO
+  __builtin_amdgcn_s_setprio(PN_WS_PRIO);        // MFMA issue ahead of the producers' VALU / LDS / VMEM issue on this SIMD
+#endif
+  const int col = nt * 32 + (lane & 31);
+  floatx16 acc[4];
+  {
+    float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
+    float br = b[N + col]; br += b[4 * N + col];// 147-153
+    const float bt = b[5 * N + col];            // 164
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
+  }
+  PnQOps<3> oA, oB;
+  // interval of tile g (LDS buffer BUF): [read q0 | MFMA q3 of tile g-1] [read q1 | MFMA q0] [read q2 | MFMA q1]
+  // [read q3 | MFMA q2] barrier; q3 is consumed at the start of the next interval
+#define WC_INTERVAL(BUF, PI2, CI2, HAVE_PREV) do {                                                         \
+    PN_SB();                                                                                               \
+    pn_lds_read_1q<3, 0>(oA, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    if (HAVE_PREV) PN_Q3ALL(oB, 0, 1, PI2);                                                                \
+    pn_lds_read_1q<3, 1>(oB, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
+    pn_lds_read_1q<3, 2>(oA, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    PN_Q3ALL(oB, 0, 1, CI2);                                                                               \
+    pn_lds_read_1q<3, 3>(oB, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
+    pn_mfma_drain();                                                                                       \
+    PN_SYNC();                                                                                             \
+  } while (0)
+  PN_SYNC();                                     // P_0
+  WC_INTERVAL(0, 2, 2, false);
+#pragma unroll 1
+  for (int g = 1; g + 1 < T1; g += 2) {
+    WC_INTERVAL(1, 2, 2, true);
+    WC_INTERVAL(0, 2, 2, true);
+  }
+  WC_INTERVAL(1, 2, 2, true);                    // tile T1-1 (T1 even)
+  WC_INTERVAL(0, 2, 3, true);                    // tile T1: first h tile; opens with q3 of the last x tile
+#pragma unroll 1
+  for (int g = T1 + 1; g + 1 < TT; g += 2) {
+    WC_INTERVAL(1, 3, 3, true);
+    WC_INTERVAL(0, 3, 3, true);
+  }
+  WC_INTERVAL(1, 3, 3, true);                    // tile TT-1
+  PN_Q3ALL(oB, 0, 1, 3);
+  pn_mfma_drain();
+#undef WC_INTERVAL
+  {
+    const float bh = b[2 * N + col];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      const float z = pn_sigmoid(acc[0][i], S.tansig);
+      const float r = pn_sigmoid(acc[1][i], S.tansig);
+      float h = bh;
+      h += acc[3][i] * r;
+      h = h + acc[2][i];
+      const float hv = pn_act(h, act, S.tansig);
+      if (row < n_rows) {
+        const float ho = h_old[(size_t)row * N + col];
+        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
+      }
+    }
+  }
+#ifdef PN_NN_CLOCKS
+  if (tid == 0 && N == 512 && blockIdx.x < 8192) {
+    unsigned long long *t = pn_nn_trace + (size_t)blockIdx.x * 4;
+    t[0] = (unsigned long long)r0_; t[1] = (unsigned long long)wall_clock64();
+    t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    atomicAdd(&pn_nn_clk[0], 1ull); atomicAdd(&pn_nn_clk[1], 1ull); atomicAdd(&pn_nn_clk[2], 1ull);
+  }
+#endif
+}
+
 // Dense / conv-as-dense with the same half-tile pipeline (KT even, >= 2).
 #define PN_DN(o, QQ, c) do {                                                                               \
     _Pragma("unroll") for (int t_ = 0; t_ < NT; t_++)                                                      \
@@ -991,6 +1166,9 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
 #ifdef PN_NN_OLD_PIPE
   hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+                     tansig, h_new, n_rows, n_mtiles);
+#elif defined(PN_NN_WS)
+  hipLaunchKernelGGL(pn_gru_mfma_ws_kernel, dim3(grid), dim3(WS_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
 #else
   hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
