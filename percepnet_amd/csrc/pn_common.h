@@ -14,6 +14,8 @@
 #define PN_NFFT 960
 #define PN_HIST_FRAMES 12       // comb_buf = 5760 samples = 12 frames (denoise.cpp:32), kept as a ring
 #define PN_HIST (PN_HIST_FRAMES * PN_FRAME)
+#define PN_HIST_STRIDE (PN_HIST + 8)   // per-stream ring + a mirror of its first 8 samples: any 4 consecutive logical samples are
+                                       // 4 consecutive floats in memory, also across the ring's wrap (unaligned dwordx4 comb-tap loads)
 #define PN_SPEC_BINS 400        // bins >= 400 never contribute (denoise.cpp:89-182)
 #define PN_PITCH_MAX 768
 #define PN_PITCH_MIN 60

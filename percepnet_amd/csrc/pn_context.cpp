@@ -161,7 +161,7 @@ static int upload(pn_ctx *c, float **dst, const float *src, size_t n) {
 
 static int zero_state(pn_ctx *c) {
   const size_t B = c->B;
-  PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST_STRIDE * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->synth, 0, B * PN_FRAME * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->yring, 0, 6 * B * PN_SPEC_BINS * sizeof(float2), c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->eyring, 0, 6 * B * 36 * 4, c->stream));
@@ -222,7 +222,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
     delete ht;
     if (rc) goto fail;
   }
-  DEV_ALLOC(c->hist, B * PN_HIST, false);
+  DEV_ALLOC(c->hist, B * PN_HIST_STRIDE, false);
   DEV_ALLOC(c->synth, B * PN_FRAME, false);
   DEV_ALLOC(c->last_gain, B, false);
   DEV_ALLOC(c->last_period, B, false);

@@ -204,13 +204,12 @@ __device__ __forceinline__ float fe_band(const FeTablesLds &T, const float2 *A, 
   return sum;
 }
 
-// logical comb_buf index j in [0,5760) (newest sample at 5759) -> ring offset
+// logical comb_buf index j in [0,5760) (newest sample at 5759) -> ring offset: (j + 480*base_slot) mod 5760
 __device__ __forceinline__ int fe_ring(int j, int base_slot) {
-  const int f = j / PN_FRAME;
-  int slot = base_slot + f;
-  if (slot >= PN_HIST_FRAMES) slot -= PN_HIST_FRAMES;
-  return slot * PN_FRAME + (j - f * PN_FRAME);
+  const int p = j + base_slot * PN_FRAME;
+  return p >= PN_HIST ? p - PN_HIST : p;
 }
+typedef float fe_f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 consecutive samples at any dword alignment
 
 // acc + sum_{j<N} a[j]*b[j], adds strictly in j order (celt_inner_prod / xcorr_kernel, pitch.h:53-144).
 // `a` is uniform within the group: ds_read_b128 at one address (16-byte aligned); b is per lane.
@@ -420,19 +419,30 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
     long long tmark_ = __builtin_readcyclecounter();
 #endif
     if (s < n_streams) {
-      float *h = hist + (size_t)s * PN_HIST;
+      float *h = hist + (size_t)s * PN_HIST_STRIDE;
       // -- history: the shift+append of denoise.cpp:388-389 becomes one ring-slot write ---------
+      {
+        constexpr int NI = (PN_FRAME / 4 + L - 1) / L;     // float4 per lane (8 at L=16, the last one partial)
+        float4 nv[NI];
 #pragma unroll
-      for (int i4 = l; i4 < PN_FRAME / 4; i4 += L) {
-        float4 v;
-        if (sizeof(TIn) == 2) {
-          const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * in_stride + 4 * i4);
-          // a power-of-two scale: the product is exact, == the reference's division (main.cpp:34)
-          v = make_float4(((float)q.x) * i16_scale, ((float)q.y) * i16_scale, ((float)q.z) * i16_scale, ((float)q.w) * i16_scale);
-        } else {
-          v = *reinterpret_cast<const float4 *>(in + (size_t)s * in_stride + 4 * i4);
+        for (int it = 0; it < NI; it++) {                  // all loads first, then the stores
+          const int i4 = l + L * it, i4c = i4 < PN_FRAME / 4 ? i4 : 0;
+          if (sizeof(TIn) == 2) {
+            const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * in_stride + 4 * i4c);
+            // a power-of-two scale: the product is exact, == the reference's division (main.cpp:34)
+            nv[it] = make_float4(((float)q.x) * i16_scale, ((float)q.y) * i16_scale, ((float)q.z) * i16_scale, ((float)q.w) * i16_scale);
+          } else {
+            nv[it] = *reinterpret_cast<const float4 *>(in + (size_t)s * in_stride + 4 * i4c);
+          }
         }
-        *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = v;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+          const int i4 = l + L * it;
+          if (i4 < PN_FRAME / 4) {
+            *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = nv[it];
+            if (new_slot == 0 && i4 < 2) *reinterpret_cast<float4 *>(h + PN_HIST + 4 * i4) = nv[it];   // mirror of the ring's first 8 samples
+          }
+        }
       }
       PN_WAVE_SYNC_GLOBAL();
       FE_MARK(0);
@@ -757,27 +767,33 @@ __global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
 #endif
       // -- comb filter (denoise.cpp:416-422) + window + FFT -> P, Ep, Exp -------------------------
       {
+        // each lane filters 4 consecutive samples per step: one (unaligned) dwordx4 load per tap instead of four
+        // dword loads — the phase is bound by the number of VMEM instructions a wave can issue, not by bytes
 #ifndef PN_FE_COMB_CH
-#define PN_FE_COMB_CH ((L == 16) ? 12 : 10)
+#define PN_FE_COMB_CH 5
 #endif
-        constexpr int CH = PN_FE_COMB_CH;               // samples per lane per chunk: 7*CH loads in flight
-        static_assert((PN_WINDOW / L) % CH == 0, "chunk");
+        constexpr int CH = PN_FE_COMB_CH;               // 4-sample groups per lane per chunk: 7*CH dwordx4 loads in flight
+        constexpr int NG = PN_WINDOW / 4 / L;           // groups per lane (15 at L=16)
+        static_assert(NG % CH == 0, "chunk");
 #pragma unroll 1
-        for (int i0 = l; i0 < PN_WINDOW; i0 += L * CH) {
-          float cv[CH][7];
+        for (int q0 = 0; q0 < NG; q0 += CH) {
+          fe_f4u cv[CH][7];
 #pragma unroll
           for (int q = 0; q < CH; q++)
 #pragma unroll
             for (int k = -PN_COMB_M; k <= PN_COMB_M; k++)
-              cv[q][k + PN_COMB_M] = h[fe_ring(2400 - pitch_index * k + i0 + L * q, base_slot)];
+              cv[q][k + PN_COMB_M] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(2400 - pitch_index * k + 4 * (l + L * (q0 + q)), base_slot));
 #pragma unroll
           for (int q = 0; q < CH; q++) {
-            const int i = i0 + L * q;
-            float p = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) p += cv[q][k] * S.comb_w[k];
-            const float v = p * S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
-            W.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+            for (int c = 0; c < 4; c++) {
+              const int i = 4 * (l + L * (q0 + q)) + c;
+              float p = 0;
+#pragma unroll
+              for (int k = 0; k < 7; k++) p += cv[q][k][c] * S.comb_w[k];
+              const float v = p * S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
+              W.fft[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+            }
           }
         }
       }

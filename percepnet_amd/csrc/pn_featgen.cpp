@@ -36,7 +36,7 @@ static int fg_alloc(pn_featgen *c, void **p, size_t bytes) {
 
 static int fg_zero_side(pn_featgen *c, FgSide &s) {
   const size_t B = c->B;
-  PN_HIP_CHECK(hipMemsetAsync(s.hist, 0, B * PN_HIST * 4, c->stream));
+  PN_HIP_CHECK(hipMemsetAsync(s.hist, 0, B * PN_HIST_STRIDE * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(s.yring, 0, 6 * B * PN_SPEC_BINS * sizeof(float2), c->stream));
   PN_HIP_CHECK(hipMemsetAsync(s.eyring, 0, 6 * B * 36 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(s.last_gain, 0, B * 4, c->stream));
@@ -81,7 +81,7 @@ extern "C" pn_featgen *pn_featgen_create(int device, int n_pairs, void *hip_stre
     if (e != hipSuccess) { pn_set_error("table upload failed: %s", hipGetErrorString(e)); goto fail; }
     FgSide *sides[2] = {&c->clean, &c->noisy};
     for (FgSide *s : sides) {
-      FG_ALLOC(s->hist, B * PN_HIST);
+      FG_ALLOC(s->hist, B * PN_HIST_STRIDE);
       FG_ALLOC(s->yring, 6 * B * PN_SPEC_BINS);
       FG_ALLOC(s->eyring, 6 * B * 36);
       FG_ALLOC(s->Ps, B * PN_SPEC_BINS);
