@@ -287,21 +287,80 @@ __device__ __forceinline__ void fe_chain2(const float *a, const float *b1, const
 // operands.  Everything that is not order-dependent is formed lane-parallel first with the reference's
 // roundings: the squares y[j]^2 for the initial energy (64 at a time into sq), the window updates
 // d[i] = y[i+LEN]^2 - y[i]^2, and the numerators num[i] = (xcorr[i]*1e-12)^2, with NaN standing for
-// "xcorr[i] <= 0: candidate skipped" (every comparison against NaN is false).  The serial scan is then
-// branch-free: two cross-multiplied comparisons and selects on the (best, second best) state, plus
-// the running-energy add + clamp, per candidate.  xcorr, d, sq 16-byte aligned; sq holds 64 floats.
+// "xcorr[i] <= 0: candidate skipped" (every comparison against NaN is false).  The serial part is then the
+// running-energy add + clamp per candidate and, only when some candidate of a group of four beats the current
+// second best, the cross-multiplied comparisons and selects on the (best, second best) state.  Every LDS
+// operand of a 64-candidate block is read before the serial chain starts (a read waited for inside the chain
+// costs its full ~120-cycle latency per four steps).  xcorr, d, sq 16-byte aligned; sq holds 64 floats.
+// sum NV4 float4 groups of sq into the serial energy chain: all LDS reads are issued before the first add
+template <int NV4>
+__device__ __forceinline__ float fe_sum_sq(const float *sq, float Syy) {
+  float4 q[NV4];
+#pragma unroll
+  for (int v = 0; v < NV4; v++) q[v] = *reinterpret_cast<const float4 *>(sq + 4 * v);
+#pragma unroll
+  for (int v = 0; v < NV4; v++) { Syy = Syy + q[v].x; Syy = Syy + q[v].y; Syy = Syy + q[v].z; Syy = Syy + q[v].w; }
+  return Syy;
+}
+
+// One candidate against the (best, second best) state; sy_ = running energy at that candidate.
+#define FE_FBP_STEP(nm_, sy_, idx_) do {                                                            \
+    const float num = (nm_);                                                                        \
+    const bool c1 = num * bd1 > bn1 * (sy_);                                                        \
+    const bool c0 = c1 && (num * bd0 > bn0 * (sy_));                                                \
+    bn1 = c0 ? bn0 : (c1 ? num : bn1); bd1 = c0 ? bd0 : (c1 ? (sy_) : bd1); bp1 = c0 ? bp0 : (c1 ? (idx_) : bp1); \
+    bn0 = c0 ? num : bn0; bd0 = c0 ? (sy_) : bd0; bp0 = c0 ? (idx_) : bp0;                          \
+  } while (0)
+#define FE_SYY_NEXT(sy_, dd_) ((1 > ((sy_) + (dd_))) ? 1 : ((sy_) + (dd_)))
+struct FeBest { float bn0, bn1, bd0, bd1; int bp0, bp1; };
+
+// NV4 groups of four candidates starting at candidate i0: operands read from LDS up front (8 groups at a time).
+// Four candidates at a time: the running energies do not depend on the search state, and a candidate changes
+// the state only if it beats the current second best — if none of the four does (in any of the wave's streams)
+// the state is the same before and after them and the selects are skipped.
+template <int NV4>
+__device__ __forceinline__ void fe_scan_groups(const float *nm, const float *d, int i0, float &Syy, FeBest &B) {
+  float bn0 = B.bn0, bn1 = B.bn1, bd0 = B.bd0, bd1 = B.bd1; int bp0 = B.bp0, bp1 = B.bp1;
+#pragma unroll
+  for (int h0 = 0; h0 < NV4; h0 += 8) {
+    constexpr int dummy = 0; (void)dummy;
+    float4 n4[8], d4[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) if (h0 + v < NV4) {
+      n4[v] = *reinterpret_cast<const float4 *>(nm + 4 * (h0 + v));
+      d4[v] = *reinterpret_cast<const float4 *>(d + 4 * (h0 + v));
+    }
+#pragma unroll
+    for (int v = 0; v < 8; v++) if (h0 + v < NV4) {
+      const int i = i0 + 4 * (h0 + v);
+      const float s0 = Syy, s1 = FE_SYY_NEXT(s0, d4[v].x), s2 = FE_SYY_NEXT(s1, d4[v].y), s3 = FE_SYY_NEXT(s2, d4[v].z);
+      Syy = FE_SYY_NEXT(s3, d4[v].w);
+      const bool any = (n4[v].x * bd1 > bn1 * s0) || (n4[v].y * bd1 > bn1 * s1) || (n4[v].z * bd1 > bn1 * s2) ||
+                       (n4[v].w * bd1 > bn1 * s3);
+      if (__ballot(any)) {
+        FE_FBP_STEP(n4[v].x, s0, i); FE_FBP_STEP(n4[v].y, s1, i + 1);
+        FE_FBP_STEP(n4[v].z, s2, i + 2); FE_FBP_STEP(n4[v].w, s3, i + 3);
+      }
+    }
+  }
+  B.bn0 = bn0; B.bn1 = bn1; B.bd0 = bd0; B.bd1 = bd1; B.bp0 = bp0; B.bp1 = bp1;
+}
+
 template <int LEN, int MAXP>
 __device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const float *y, float *sq, float *d, int l,
                                                    int &bp0_out, int &bp1_out) {
   constexpr int MP4 = (MAXP + 3) & ~3;
+  static_assert(LEN % 4 == 0, "LEN");
   for (int i = l; i < MP4; i += L) {
     const int ic = i < MAXP ? i : MAXP - 1;
     const float a = y[ic + LEN], c = y[ic];
     d[i] = a * a - c * c;
   }
+  // initial energy Syy = 1 + sum_{j<LEN} y[j]^2, j ascending (pitch.cpp:62-63); squares lane-parallel 64 at a time
   float Syy = 1.0f;
+  constexpr int FULL_Y = LEN / 64, TAIL_Y = (LEN % 64) / 4;
 #pragma unroll 1
-  for (int blk = 0; blk < (LEN + 63) / 64; blk++) {
+  for (int blk = 0; blk < FULL_Y + (TAIL_Y ? 1 : 0); blk++) {
     float yv[64 / L];
 #pragma unroll
     for (int w = 0; w < 64 / L; w++) { const int j = 64 * blk + l + L * w; yv[w] = y[j < LEN ? j : 0]; }
@@ -309,27 +368,13 @@ __device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const flo
 #pragma unroll
     for (int w = 0; w < 64 / L; w++) sq[l + L * w] = yv[w] * yv[w];
     PN_WAVE_SYNC();
-#pragma unroll
-    for (int v = 0; v < 16; v++) {
-      if (64 * blk + 4 * v < LEN) {
-        const float4 q = *reinterpret_cast<const float4 *>(sq + 4 * v);
-        Syy = Syy + q.x; Syy = Syy + q.y; Syy = Syy + q.z; Syy = Syy + q.w;
-      }
-    }
+    if (blk < FULL_Y) Syy = fe_sum_sq<16>(sq, Syy);
+    else Syy = fe_sum_sq<TAIL_Y ? TAIL_Y : 1>(sq, Syy);
   }
-  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-  int bp0 = 0, bp1 = 1;
-#define FE_FBP_STEP(nm_, dd_, idx_) do {                                                            \
-    const float num = (nm_);                                                                        \
-    const bool c1 = num * bd1 > bn1 * Syy;                                                          \
-    const bool c0 = c1 && (num * bd0 > bn0 * Syy);                                                  \
-    bn1 = c0 ? bn0 : (c1 ? num : bn1); bd1 = c0 ? bd0 : (c1 ? Syy : bd1); bp1 = c0 ? bp0 : (c1 ? (idx_) : bp1); \
-    bn0 = c0 ? num : bn0; bd0 = c0 ? Syy : bd0; bp0 = c0 ? (idx_) : bp0;                            \
-    Syy += (dd_);                                                                                   \
-    Syy = (1 > Syy) ? 1 : Syy;                                                                      \
-  } while (0)
+  FeBest B = {-1.f, -1.f, 0.f, 0.f, 0, 1};
+  constexpr int FULL_C = MP4 / 64, TAIL_C = (MP4 % 64) / 4;
 #pragma unroll 1
-  for (int blk = 0; blk < (MAXP + 63) / 64; blk++) {
+  for (int blk = 0; blk < FULL_C + (TAIL_C ? 1 : 0); blk++) {
     float nv[64 / L];
 #pragma unroll
     for (int w = 0; w < 64 / L; w++) {
@@ -337,26 +382,19 @@ __device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const flo
       const float xc = xcorr[i < MAXP ? i : 0];
       float x16 = xc;
       x16 *= 1e-12f;
-      nv[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");
+      nv[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");   // NaN: skipped (every comparison false)
     }
     PN_WAVE_SYNC();
 #pragma unroll
     for (int w = 0; w < 64 / L; w++) sq[l + L * w] = nv[w];
     PN_WAVE_SYNC();
-#pragma unroll
-    for (int v = 0; v < 16; v++) {
-      const int i = 64 * blk + 4 * v;
-      if (i < MAXP) {
-        const float4 n4 = *reinterpret_cast<const float4 *>(sq + 4 * v);
-        const float4 d4 = *reinterpret_cast<const float4 *>(d + i);
-        FE_FBP_STEP(n4.x, d4.x, i); FE_FBP_STEP(n4.y, d4.y, i + 1);
-        FE_FBP_STEP(n4.z, d4.z, i + 2); FE_FBP_STEP(n4.w, d4.w, i + 3);
-      }
-    }
+    if (blk < FULL_C) fe_scan_groups<16>(sq, d + 64 * blk, 64 * blk, Syy, B);
+    else fe_scan_groups<TAIL_C ? TAIL_C : 1>(sq, d + 64 * blk, 64 * blk, Syy, B);
   }
-#undef FE_FBP_STEP
-  bp0_out = bp0; bp1_out = bp1;
+  bp0_out = B.bp0; bp1_out = B.bp1;
 }
+#undef FE_SYY_NEXT
+#undef FE_FBP_STEP
 
 // Tuning aid (variant builds with -DPN_FE_CLOCKS only): wave 0 of every block accumulates the shader-clock
 // cycles between phase marks into pn_fe_clk[]; read back with pn_fe_clocks_read().
