@@ -50,6 +50,25 @@ __device__ __forceinline__ float pn_tansig(float x, const float *tab) {
   y = y + x * dy * (1 - y * x);
   return sign * y;
 }
+// the same function in two halves, so that callers can issue many table reads before using any of them
+struct PnTsArg { float sign, x; int i; };
+__device__ __forceinline__ PnTsArg pn_tansig_arg(float x) {
+  PnTsArg a;
+  a.sign = 1;
+  if (x < 0) { x = -x; a.sign = -1; }
+  const float v = floorf(.5f + 25 * x);
+  int i = (v < 2147483648.f) ? (int)v : (int)0x80000000;
+  i = i > 200 ? 200 : i;
+  i = i < 0 ? 0 : i;
+  a.x = x - .04f * i;
+  a.i = i;
+  return a;
+}
+__device__ __forceinline__ float pn_tansig_fin(const PnTsArg &a, float y) {
+  const float dy = 1 - y * y;
+  y = y + a.x * dy * (1 - y * a.x);
+  return a.sign * y;
+}
 __device__ __forceinline__ float pn_sigmoid(float x, const float *tab) { return .5f + .5f * pn_tansig(.5f * x, tab); }
 __device__ __forceinline__ float pn_act(float v, int act, const float *tab) {
   if (act == ACT_SIGMOID) return pn_sigmoid(v, tab);
