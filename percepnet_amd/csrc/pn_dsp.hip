@@ -177,48 +177,76 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
   PnDspWaveLds &W = SH.w[wave];
   const float scale = 1.f / PN_NFFT;
   for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
+    // global operands are read in batches ahead of their use (a load waited for inside the loop costs its full
+    // latency every iteration); three batches of five keep the kernel at 4 waves per SIMD without spills
+    float smv[(PN_FRAME + LANES - 1) / LANES];
+#pragma unroll
+    for (int it = 0; it < (PN_FRAME + LANES - 1) / LANES; it++) {
+      const int i = lane + LANES * it;
+      smv[it] = synth_mem[(size_t)s * PN_FRAME + (i < PN_FRAME ? i : 0)];
+    }
+    const bool sil = silence[s] != 0;
     if (lane < PN_NB) {
       const float g = gr[(size_t)s * 68 + lane], r = gr[(size_t)s * 68 + PN_NB + lane];
       W.e[0][lane] = g; W.e[1][lane] = r; W.e[2][lane] = 1 - r;
     }
     PN_WAVE_SYNC();
-    const bool sil = silence[s] != 0;
     // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian
     // extension + scale + digit-reverse scatter of inverse_transform (306-317).  Bins >= 400
     // are exactly 0 (interp_band_gain never writes them).
-#pragma unroll 3
-    for (int it = 0; it < 15; it++) {
-      const int i = lane + LANES * it;
-      const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
-      float2 x = make_float2(0.f, 0.f);
-      if (k < PN_SPEC_BINS) {
-        x = Xspec[(size_t)s * PN_SPEC_BINS + k];
-        const int b = S.band[k];
-        const float fr = S.frac[k];
-        if (!sil) {
-          const float2 p = Pspec[(size_t)s * PN_SPEC_BINS + k];
-          const float rf1 = (1 - fr) * W.e[2][b] + fr * W.e[2][b + 1];
-          x.x = rf1 * x.x; x.y = rf1 * x.y;
-          const float rf2 = (1 - fr) * W.e[1][b] + fr * W.e[1][b + 1];
-          x.x += rf2 * p.x; x.y += rf2 * p.y;
+#pragma unroll 1
+    for (int h0 = 0; h0 < 15; h0 += 5) {
+      float2 xv[5], pv[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        if (h0 + u < 15) {
+          const int i = lane + LANES * (h0 + u);
+          const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
+          const int kc = k < PN_SPEC_BINS ? k : PN_SPEC_BINS - 1;
+          xv[u] = Xspec[(size_t)s * PN_SPEC_BINS + kc];
+          pv[u] = Pspec[(size_t)s * PN_SPEC_BINS + kc];
         }
-        const float gf = (1 - fr) * W.e[0][b] + fr * W.e[0][b + 1];
-        x.x *= gf; x.y *= gf;
       }
-      if (i > PN_FRAME) x.y = -x.y;
-      W.fft[S.bitrev[i]] = make_float2(scale * x.x, scale * x.y);
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        if (h0 + u < 15) {
+          const int i = lane + LANES * (h0 + u);
+          const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
+          float2 x = make_float2(0.f, 0.f);
+          if (k < PN_SPEC_BINS) {
+            x = xv[u];
+            const int b = S.band[k];
+            const float fr = S.frac[k];
+            if (!sil) {
+              const float2 p = pv[u];
+              const float rf1 = (1 - fr) * W.e[2][b] + fr * W.e[2][b + 1];
+              x.x = rf1 * x.x; x.y = rf1 * x.y;
+              const float rf2 = (1 - fr) * W.e[1][b] + fr * W.e[1][b + 1];
+              x.x += rf2 * p.x; x.y += rf2 * p.y;
+            }
+            const float gf = (1 - fr) * W.e[0][b] + fr * W.e[0][b + 1];
+            x.x *= gf; x.y *= gf;
+          }
+          if (i > PN_FRAME) x.y = -x.y;
+          W.fft[S.bitrev[i]] = make_float2(scale * x.x, scale * x.y);
+        }
+      }
     }
     pn_fft960_lds(W.fft, S.tw, lane);
     // reversed read-out x960 (318-323), window, overlap-add (352-359)
     float *sm = synth_mem + (size_t)s * PN_FRAME;
-    for (int i = lane; i < PN_FRAME; i += LANES) {
-      const float t_lo = (PN_WINDOW * W.fft[i == 0 ? 0 : PN_WINDOW - i].x) * S.win[i];
-      const int i2 = PN_FRAME + i;                       // second half, window index 959 - i2
-      const float t_hi = (PN_WINDOW * W.fft[PN_WINDOW - i2].x) * S.win[PN_WINDOW - 1 - i2];
-      const float o = t_lo + sm[i];
-      sm[i] = t_hi;
-      if (sizeof(TOut) == 2) out[(size_t)s * PN_FRAME + i] = (TOut)pn_f2s(o * 32768);
-      else out[(size_t)s * PN_FRAME + i] = (TOut)o;
+#pragma unroll
+    for (int it = 0; it < (PN_FRAME + LANES - 1) / LANES; it++) {
+      const int i = lane + LANES * it;
+      if (i < PN_FRAME) {
+        const float t_lo = (PN_WINDOW * W.fft[i == 0 ? 0 : PN_WINDOW - i].x) * S.win[i];
+        const int i2 = PN_FRAME + i;                       // second half, window index 959 - i2
+        const float t_hi = (PN_WINDOW * W.fft[PN_WINDOW - i2].x) * S.win[PN_WINDOW - 1 - i2];
+        const float o = t_lo + smv[it];
+        sm[i] = t_hi;
+        if (sizeof(TOut) == 2) out[(size_t)s * PN_FRAME + i] = (TOut)pn_f2s(o * 32768);
+        else out[(size_t)s * PN_FRAME + i] = (TOut)o;
+      }
     }
     PN_WAVE_SYNC();
   }
