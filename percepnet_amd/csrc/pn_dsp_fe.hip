@@ -40,7 +40,10 @@
 #endif
 #define G PN_FE_G
 #define L (LANES / G)           // lanes per stream
-#define FE_WPB (16 / G)         // waves per block: 16 streams per block (146 KB LDS, one block per CU)
+#ifndef PN_FE_SPB
+#define PN_FE_SPB 16            // streams per block: 16 = 146 KB LDS, one block per CU; 8 = 80 KB (can share a CU with a GEMM block)
+#endif
+#define FE_WPB (PN_FE_SPB / G)  // waves per block
 #define NCH ((147 + L - 1) / L) // coarse-search lags per lane
 #define NBND ((PN_NB + L - 1) / L)
 #define FE_THREADS (LANES * FE_WPB)
@@ -415,7 +418,7 @@ extern "C" int pn_fe_clocks_read(unsigned long long *out, int reset) {
 __device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
 
 template <typename TIn>
-__global__ __launch_bounds__(FE_THREADS, (FE_WPB / 4)) void pn_frontend_kernel(
+__global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
     const TIn *__restrict__ in,           // stream s's frame at in + s*in_stride (480 contiguous samples)
     long long in_stride, float i16_scale, // int16 input: sample = (float)v * i16_scale (2^-15: main.cpp:34; 1: denoise.cpp:41,697)
@@ -898,7 +901,8 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_
                         int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
                         float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
   const int need = (n_streams + FE_SPB - 1) / FE_SPB;
-  const int grid = need < 256 ? need : 256;            // one 146 KB block per CU, grid-stride
+  const int cap = 256 * (16 / FE_SPB);                 // LDS-resident blocks on 256 CUs
+  const int grid = need < cap ? need : cap;            // grid-stride
   const int frame_t = (int)(frame % PN_HIST_FRAMES);
   const int slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
   if (in_is_i16)

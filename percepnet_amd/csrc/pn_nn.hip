@@ -114,6 +114,9 @@ struct NnShared {
   float A[2][BM][LDT];       // 2 x 18432 B   double-buffered K-tiles
   float B[2][4 * 32][LDT];   // 2 x 18432 B   (up to 4 column tiles: dense NT<=4, GRU 3 gates)
   float tansig[208];
+#ifdef PN_NN_LDS_PAD            // experiment: more than half of the CU's LDS -> at most one GEMM block per CU
+  float pad[PN_NN_LDS_PAD];
+#endif
 };
 
 // ---- software-pipelined staging: global -> registers (issued before the MFMAs of the current

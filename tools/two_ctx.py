@@ -20,5 +20,9 @@ def run(t0, t1):
         for c, o in zip(ctxs, outs):
             c.process_i16_dev(frames[t].data_ptr(), o.data_ptr(), None)
 run(0, 2); torch.cuda.synchronize()
+SKEW = int(os.environ.get("PN_SKEW_CYCLES", "0"))          # delay the second context once: anti-phase start
+if SKEW and NC > 1:
+    with torch.cuda.stream(streams[1]):
+        torch.cuda._sleep(SKEW)
 t0 = time.perf_counter(); run(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"PN_FE_BPC={os.environ.get('PN_FE_BPC','-')} ctx={NC} x {B}: {1e3*dt/K:.3f} ms/step-pair -> {NC*B*K/dt/100:.0f} streams")
+print(f"lib={os.environ.get('PERCEPNET_LIB','default').split('/')[-2] if os.environ.get('PERCEPNET_LIB') else 'default'} skew={SKEW} ctx={NC} x {B}: {1e3*dt/K:.3f} ms/step-pair -> {NC*B*K/dt/100:.0f} streams")
