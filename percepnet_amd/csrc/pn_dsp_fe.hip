@@ -610,7 +610,7 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
       }
       FE_MARK(5);   // autocorr + LPC
       // celt_fir5 (pitch.cpp:106-145): out of place, raw -> pbuf
-#pragma unroll 2
+#pragma unroll 6
       for (int i = l; i < 864; i += L) {
         float sum = raw[i];
         sum = sum + lpc2[0] * (i >= 1 ? raw[i - 1] : 0.f);
@@ -745,15 +745,24 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
             for (int w = 0; w < 64 / L; w++) { pq[l + L * w] = pa[w]; pq[64 + l + L * w] = qa[w]; }
             PN_WAVE_SYNC();
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-              const float4 p4 = *reinterpret_cast<const float4 *>(pq + 4 * v);
-              const float4 q4 = *reinterpret_cast<const float4 *>(pq + 64 + 4 * v);
-              float4 o;
-              yy = yy + p4.x - q4.x; o.x = (0 > yy) ? 0 : yy;
-              yy = yy + p4.y - q4.y; o.y = (0 > yy) ? 0 : yy;
-              yy = yy + p4.z - q4.z; o.z = (0 > yy) ? 0 : yy;
-              yy = yy + p4.w - q4.w; o.w = (0 > yy) ? 0 : yy;
-              if (l == 0) *reinterpret_cast<float4 *>(yyl + 1 + 64 * blk + 4 * v) = o;
+            for (int h0 = 0; h0 < 16; h0 += 8) {       // operands of 32 steps read before the chain, results stored after it
+              float4 p4[8], q4[8], o[8];
+#pragma unroll
+              for (int v = 0; v < 8; v++) {
+                p4[v] = *reinterpret_cast<const float4 *>(pq + 4 * (h0 + v));
+                q4[v] = *reinterpret_cast<const float4 *>(pq + 64 + 4 * (h0 + v));
+              }
+#pragma unroll
+              for (int v = 0; v < 8; v++) {
+                yy = yy + p4[v].x - q4[v].x; o[v].x = (0 > yy) ? 0 : yy;
+                yy = yy + p4[v].y - q4[v].y; o[v].y = (0 > yy) ? 0 : yy;
+                yy = yy + p4[v].z - q4[v].z; o[v].z = (0 > yy) ? 0 : yy;
+                yy = yy + p4[v].w - q4[v].w; o[v].w = (0 > yy) ? 0 : yy;
+              }
+              if (l == 0) {
+#pragma unroll
+                for (int v = 0; v < 8; v++) *reinterpret_cast<float4 *>(yyl + 1 + 64 * blk + 4 * (h0 + v)) = o[v];
+              }
             }
           }
         }
