@@ -46,6 +46,19 @@
 #define FE_WPB (PN_FE_SPB / G)  // waves per block
 #define NCH ((147 + L - 1) / L) // coarse-search lags per lane
 #define NBND ((PN_NB + L - 1) / L)
+// Band -> (lane, slot) assignment of the band reductions.  The lanes of a group run slot c in lock-step, so a slot costs
+// as much as its widest band (ERB bands grow from 2 to 96 bins): slot 0 takes the 16 widest bands, slot 1 the next 16,
+// slot 2 the rest -> 13 + 2 + 2 eight-bin steps instead of 1 + 11 + 13 with the natural b = l + 16 c.  Any permutation
+// is correct; this one is tuned for the 34-band table of erbband.h.
+#if PN_FE_G == 4
+__device__ const uint8_t kFeBandMap[16][4] = {
+    {32, 2, 18, 34}, {31, 3, 0, 34},  {30, 4, 34, 34},  {29, 5, 34, 34},  {28, 6, 34, 34},  {27, 7, 34, 34},
+    {33, 8, 34, 34}, {25, 9, 34, 34}, {26, 10, 34, 34}, {24, 11, 34, 34}, {20, 12, 34, 34}, {21, 13, 34, 34},
+    {22, 14, 34, 34}, {23, 15, 34, 34}, {19, 16, 34, 34}, {1, 17, 34, 34}};
+#define FE_BAND_OF(S_, l_, c_) ((int)(S_).bmap[(l_) * 4 + (c_)])
+#else
+#define FE_BAND_OF(S_, l_, c_) ((l_) + L * (c_))
+#endif
 #define FE_THREADS (LANES * FE_WPB)
 #define FE_SPB (FE_WPB * G)     // streams per block
 
@@ -59,6 +72,7 @@ struct alignas(16) FeTablesLds {
   int16_t bitrev[PN_NFFT];       // 1920 B
   int16_t border[PN_NB + 2];
   uint8_t band[PN_SPEC_BINS];
+  uint8_t bmap[64];              // band handled by (lane l, slot c) at [l * 4 + c]; 34 = none
   float comb_w[8];
 };
 struct alignas(16) FeStreamLds {
@@ -443,6 +457,9 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
     for (int i = tid; i < PN_SPEC_BINS; i += FE_THREADS) { S.frac[i] = T->bin_frac[i]; S.band[i] = T->bin_band[i]; }
     if (tid < PN_NB + 2) S.border[tid] = T->border[tid];
     if (tid < 8) S.comb_w[tid] = T->comb_hann[tid];
+#if PN_FE_G == 4
+    if (tid < 64) S.bmap[tid] = kFeBandMap[tid >> 2][tid & 3];
+#endif
     __syncthreads();
   }
   const FeTablesLds &S = SH.t;
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
         float *ew = eyring + ((size_t)slot_w * n_streams + s) * 36;
 #pragma unroll
         for (int c = 0; c < NBND; c++) {
-          const int b = l + L * c;
+          const int b = FE_BAND_OF(S, l, c);
           const float e = fe_band<false>(S, W.fft, nullptr, b);
           if (b < PN_NB) { ew[b] = e; W.e[1][b] = e; }          // Ey of this frame (features)
         }
@@ -873,13 +890,13 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
       FE_MARK(16);  // Pspec store + X.P products
       float Ep[NBND];
 #pragma unroll
-      for (int c = 0; c < NBND; c++) Ep[c] = fe_band<false>(S, W.fft, nullptr, l + L * c);
+      for (int c = 0; c < NBND; c++) Ep[c] = fe_band<false>(S, W.fft, nullptr, FE_BAND_OF(S, l, c));
       PN_WAVE_SYNC();
       FE_MARK(17);  // Ep bands
       float *f = feat + (size_t)s * PN_FEAT_STRIDE;
 #pragma unroll
       for (int c = 0; c < NBND; c++) {
-        const int b = l + L * c;
+        const int b = FE_BAND_OF(S, l, c);
         float Exp = fe_band<true>(S, nullptr, prod, b);
         if (b < PN_NB) {
           const float Ex = W.e[0][b];
