@@ -102,7 +102,16 @@ __device__ __forceinline__ void pn_mfma_drain() {
 #ifndef PN_BLOCK_SKEW
 #define PN_BLOCK_SKEW 0
 #endif
+// Experiment (-DPN_BLOCK_PRIO=n): raise the issue priority of the block that sits in the upper half of the CU's LDS, so
+// that the two co-resident blocks are not arbitrated by age alone.
+__device__ __forceinline__ void pn_block_prio() {
+#ifdef PN_BLOCK_PRIO
+  const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);      // HW_REG_LDS_ALLOC: [7:0] base, [20:12] size
+  if ((la & 0xff) != 0) __builtin_amdgcn_s_setprio(PN_BLOCK_PRIO);
+#endif
+}
 __device__ __forceinline__ void pn_block_skew() {
+  pn_block_prio();
 #if PN_BLOCK_SKEW > 0
   if (blockIdx.x >= 256 && blockIdx.x < 512) {
 #pragma unroll

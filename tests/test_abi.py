@@ -52,3 +52,27 @@ def test_model_parsing_and_error_paths_without_gpu(lib, blob):
         with pytest.raises(api.PercepNetError):
             api.FeatGen(4)
     m.close()
+
+
+def test_header_is_plain_c_and_a_c_caller_links(lib, blob, tmp_path):
+    """gcc -std=c99 compiles a caller against include/percepnet_hip.h and links libpercepnet_hip.so; without a GPU it
+    must report the missing device through pn_last_error() and exit cleanly (never fall back to a CPU path)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(api.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-L" + libdir,
+                           "-lpercepnet_hip", "-Wl,-rpath," + libdir])
+    mp = tmp_path / "model.pnw"
+    mp.write_bytes(blob)
+    r = subprocess.run([str(exe), str(mp)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "percepnet_hip" in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "no context" in r.stdout and "HIP" in r.stdout
+    else:
+        assert "process rc=0" in r.stdout
