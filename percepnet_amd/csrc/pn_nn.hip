@@ -703,11 +703,19 @@ __device__ __forceinline__ void pn_lds_read_1q(PnQOps<NB> &o, const float (*As)[
 #define PN_Q3ALL(o, I0, I1, I2) do { PN_Q3(o, x, I0, I1, I2); PN_Q3(o, y, I0, I1, I2); PN_Q3(o, z, I0, I1, I2); \
                                      PN_Q3(o, w, I0, I1, I2); } while (0)
 
-__global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
+// NG consumer groups of four waves (128 rows each) + four producer waves: NG = 1 -> 8 waves, two blocks per CU (4 waves per
+// SIMD, <= 128 registers); NG = 2 -> 12 waves, one block per CU (3 waves per SIMD), the weight tile shared by 256 rows.
+template <int NG> struct NnSharedWs {
+  float A[2][NG * BM][LDT];
+  float B[2][3 * 32][LDT];
+  float tansig[208];
+};
+template <int NG>
+__global__ __launch_bounds__(256 * (NG + 1), (NG == 1 ? 4 : 3)) void pn_gru_mfma_ws_kernel(
     PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
     const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
     float *__restrict__ h_new, int n_rows, int n_mtiles) {
-  __shared__ NnShared S;
+  __shared__ NnSharedWs<NG> S;
   const int NTn = N >> 5;
   int mt, nt;
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
@@ -715,27 +723,27 @@ __global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
   const long long r0_ = wall_clock64();
 #endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = mt * BM, KTh = N >> 5;
+  const int m0 = mt * (NG * BM), KTh = N >> 5;
   const int T1 = KTx, TT = KTx + KTh;
   if (tid < 201) S.tansig[tid] = tansig[tid];
 
-  if (wave >= 4) {
+  if (wave >= 4 * NG) {
     // ------------------------------------------------ producers ------------------------------------------
     const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
                 *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
     const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
                 *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
     PN_PANEL_LOCALS(X);
-    const int ptid = tid - 256;
-    unsigned aox[4], aoh[4];
+    const int ptid = tid - 256 * NG;
+    unsigned aox[4 * NG], aoh[4 * NG];
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
+    for (int it = 0; it < 4 * NG; it++) {
       const int idx = ptid + NN_THREADS * it;
       aox[it] = (unsigned)(((idx >> 3) * pld + 4 * (idx & 7)) * 4);
       aoh[it] = (unsigned)(((idx >> 3) * N + 4 * (idx & 7)) * 4);
     }
     const unsigned bo4 = (unsigned)(ptid * 16);
-    PnTileRegs<3> R0, R1;
+    struct { float4 a[4 * NG]; float4 b[3]; } R0, R1;
 #define WS_SEL(gg)                                                                                        \
     int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
     const bool p1_ = g_ < T1;                                                                              \
@@ -745,11 +753,11 @@ __global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
     const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
     const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
 #define WS_FETCH(R, gg) do { WS_SEL(gg);                                                                   \
-    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) (R).a[it_] = pn_load_so(ap_, p1_ ? aox[it_] : aoh[it_]); \
+    _Pragma("unroll") for (int it_ = 0; it_ < 4 * NG; it_++) (R).a[it_] = pn_load_so(ap_, p1_ ? aox[it_] : aoh[it_]); \
     (R).b[0] = pn_load_so(bz_, bo4); (R).b[1] = pn_load_so(br_, bo4); (R).b[2] = pn_load_so(bh_, bo4); } while (0)
     // the stash helpers index by threadIdx.x & 255 == ptid for the producer half of the block
 #define WS_STASH(R, BUF) do {                                                                              \
-    _Pragma("unroll") for (int it_ = 0; it_ < 4; it_++) {                                                  \
+    _Pragma("unroll") for (int it_ = 0; it_ < 4 * NG; it_++) {                                             \
       const int idx_ = ptid + NN_THREADS * it_; const int row_ = idx_ >> 3, c_ = idx_ & 7;                 \
       float *dst_ = &S.A[BUF][row_][(c_ >> 1) * 8 + 2 * (c_ & 1)];                                         \
       *reinterpret_cast<float2 *>(dst_) = make_float2((R).a[it_].x, (R).a[it_].z);                         \
@@ -779,6 +787,7 @@ __global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
 #ifdef PN_WS_PRIO
   __builtin_amdgcn_s_setprio(PN_WS_PRIO);        // MFMA issue ahead of the producers' VALU / LDS / VMEM issue on this SIMD
 #endif
+  const int cw = wave & 3, grp = wave >> 2;      // 32-row strip inside a 128-row group
   const int col = nt * 32 + (lane & 31);
   floatx16 acc[4];
   {
@@ -793,13 +802,13 @@ __global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
   // [read q3 | MFMA q2] barrier; q3 is consumed at the start of the next interval
 #define WC_INTERVAL(BUF, PI2, CI2, HAVE_PREV) do {                                                         \
     PN_SB();                                                                                               \
-    pn_lds_read_1q<3, 0>(oA, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    pn_lds_read_1q<3, 0>(oA, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
     if (HAVE_PREV) PN_Q3ALL(oB, 0, 1, PI2);                                                                \
-    pn_lds_read_1q<3, 1>(oB, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    pn_lds_read_1q<3, 1>(oB, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
     PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
-    pn_lds_read_1q<3, 2>(oA, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    pn_lds_read_1q<3, 2>(oA, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
     PN_Q3ALL(oB, 0, 1, CI2);                                                                               \
-    pn_lds_read_1q<3, 3>(oB, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                     \
+    pn_lds_read_1q<3, 3>(oB, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
     PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
     pn_mfma_drain();                                                                                       \
     PN_SYNC();                                                                                             \
@@ -829,8 +838,8 @@ __global__ __launch_bounds__(WS_THREADS, 4) void pn_gru_mfma_ws_kernel(
     float ho[16];
 #pragma unroll
     for (int i = 0; i < 16; i++)
-      ho[i] = h_old[(size_t)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
+      ho[i] = h_old[(size_t)(m0 + BM * grp + 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
+    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, N, col, m0 + BM * grp + 32 * cw + 4 * (lane >> 5), n_rows);
   }
 #ifdef PN_NN_CLOCKS
   if (tid == 0 && N == 512 && blockIdx.x < 8192) {
@@ -1202,8 +1211,17 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
   hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
 #elif defined(PN_NN_WS)
-  hipLaunchKernelGGL(pn_gru_mfma_ws_kernel, dim3(grid), dim3(WS_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+#if PN_NN_WS == 2
+  {
+    const int n_mt2 = (n_rows + 2 * BM - 1) / (2 * BM);
+    const int grid2 = 8 * ((n_mt2 + 7) / 8) * NTn;
+    hipLaunchKernelGGL(pn_gru_mfma_ws_kernel<2>, dim3(grid2), dim3(768), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+                       tansig, h_new, n_rows, n_mt2);
+  }
+#else
+  hipLaunchKernelGGL(pn_gru_mfma_ws_kernel<1>, dim3(grid), dim3(512), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
+#endif
 #else
   hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
