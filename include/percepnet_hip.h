@@ -102,7 +102,8 @@ int pn_ctx_kernel_time(pn_ctx *ctx, const char *name, double *total_ms, int64_t 
 int pn_ctx_reset_profile(pn_ctx *ctx);
 
 /* Debug tap (tests/tools): copy an internal device buffer to the host; which = 0 feat, 1 c1ring,
-   2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r.  Returns bytes copied or -1. */
+   2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r, 10 look-ahead spectra ring, 11 comb-filtered
+   spectrum, 12 history ring.  Returns bytes copied or -1. */
 long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_bytes);
 
 /* ---- batched training-feature generator ----------------------------------- */

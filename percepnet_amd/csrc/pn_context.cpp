@@ -463,6 +463,9 @@ extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long lon
     case 4: case 5: case 6: case 7: src = c->gru[which - 4]; n = 2 * Bp * 512 * 4; break;
     case 8: src = c->rb; n = 2 * Bp * 128 * 4; break;
     case 9: src = c->gr; n = B * 68 * 4; break;
+    case 10: src = c->yring; n = 6 * B * PN_SPEC_BINS * sizeof(float2); break;     // look-ahead spectra ring [6][B][400]
+    case 11: src = c->Ps; n = B * PN_SPEC_BINS * sizeof(float2); break;            // comb-filtered spectrum [B][400]
+    case 12: src = c->hist; n = B * PN_HIST_STRIDE * 4; break;                     // history ring
     default: pn_set_error("bad debug buffer id"); return -1;
   }
   if ((long long)n > max_bytes) { pn_set_error("debug buffer needs %zu bytes", n); return -1; }

@@ -60,8 +60,101 @@ __device__ __forceinline__ void pn_stage_tables(PnDspTablesLds &S, const PnTable
 // ---- 960-point FFT in LDS (opus_fft_impl, kiss_fft.cpp:518-564, factors 5,3,4,4,4) -----------
 // Input must already be scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585).
 
-#include "pn_fft960.h"
-#define pn_fft960_lds(F_, tw_, lane_) pn_fft960<LANES, 3>(F_, tw_, lane_)
+#define CMUL(m, a, b) do { (m).x = (a).x*(b).x - (a).y*(b).y; (m).y = (a).x*(b).y + (a).y*(b).x; } while (0)
+
+__device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw, int lane) {
+  PN_WAVE_SYNC();
+  // radix-4, m=1 (degenerate twiddle-free butterfly, kiss_fft.cpp:112-131)
+  for (int b = lane; b < 240; b += LANES) {
+    float2 *f = F + 4 * b;
+    float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
+    s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
+    f0.x += f2.x; f0.y += f2.y;
+    s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
+    f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
+    f0.x += s1.x; f0.y += s1.y;
+    s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
+    f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
+    f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
+    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
+  }
+  PN_WAVE_SYNC();
+  // radix-4, m=4 (fstride 60, mm 16) then m=16 (fstride 15, mm 64)  (kiss_fft.cpp:139-166)
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int m = pass ? 16 : 4, fs = pass ? 15 : 60, mm = pass ? 64 : 16;
+    for (int b = lane; b < 240; b += LANES) {
+      const int i = b / m, j = b % m;
+      float2 *f = F + i * mm + j;
+      float2 f0 = f[0], fm = f[m], f2m = f[2 * m], f3m = f[3 * m];
+      const float2 t1 = tw[j * fs], t2 = tw[2 * j * fs], t3 = tw[3 * j * fs];
+      float2 s0, s1, s2, s3, s4, s5;
+      CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
+      s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
+      f0.x += s1.x; f0.y += s1.y;
+      s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
+      s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
+      f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
+      f0.x += s3.x; f0.y += s3.y;
+      fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
+      f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
+      f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
+    }
+    PN_WAVE_SYNC();
+  }
+  // radix-3, m=64, fstride 5, mm 192 (kiss_fft.cpp:196-227); epi3 = tw[fstride*m]
+  {
+    const float epi3 = tw[320].y;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int j = lane;
+      float2 *f = F + i * 192 + j;
+      float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
+      CMUL(s1, fm, tw[j * 5]); CMUL(s2, f2m, tw[2 * j * 5]);
+      s3.x = s1.x + s2.x; s3.y = s1.y + s2.y;
+      s0.x = s1.x - s2.x; s0.y = s1.y - s2.y;
+      fm.x = f0.x - s3.x * .5f; fm.y = f0.y - s3.y * .5f;
+      s0.x *= epi3; s0.y *= epi3;
+      f0.x += s3.x; f0.y += s3.y;
+      f2m.x = fm.x + s0.y; f2m.y = fm.y - s0.x;
+      fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
+      f[0] = f0; f[64] = fm; f[128] = f2m;
+    }
+    PN_WAVE_SYNC();
+  }
+  // radix-5, m=192, fstride 1 (kiss_fft.cpp:259-304); ya = tw[m], yb = tw[2m]
+  {
+    const float2 ya = tw[192], yb = tw[384];
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const int u = lane + LANES * it;
+      float2 *f = F + u;
+      float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
+      float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
+      CMUL(s1, f1, tw[u]); CMUL(s2, f2, tw[2 * u]); CMUL(s3, f3, tw[3 * u]); CMUL(s4, f4, tw[4 * u]);
+      s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
+      s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
+      s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
+      s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
+      f0.x = f0.x + (s7.x + s8.x);
+      f0.y = f0.y + (s7.y + s8.y);
+      s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
+      s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
+      s6.x = s10.y * ya.y + s9.y * yb.y;
+      s6.y = -(s10.x * ya.y + s9.x * yb.y);
+      f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
+      f4.x = s5.x + s6.x; f4.y = s5.y + s6.y;
+      s11.x = s0.x + (s7.x * yb.x + s8.x * ya.x);
+      s11.y = s0.y + (s7.y * yb.x + s8.y * ya.x);
+      s12.x = s9.y * ya.y - s10.y * yb.y;
+      s12.y = s10.x * yb.y - s9.x * ya.y;
+      f2.x = s11.x + s12.x; f2.y = s11.y + s12.y;
+      f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
+      f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
+    }
+    PN_WAVE_SYNC();
+  }
+}
 
 // float -> int16 as the reference CLI's x86-64 build does it (main.cpp:36): truncate toward zero
 // to int32 (cvttss2si; NaN / out of range -> 0x80000000), keep the low 16 bits.

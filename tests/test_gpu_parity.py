@@ -325,3 +325,30 @@ def test_multi_frame_device_api(model, oracle):
         assert np.array_equal(out[1:, s].reshape(-1), ro[s])
         assert np.array_equal(gr[:, s], rg[s])
     ctx.close()
+
+
+def test_placement_invariance_across_grid_stride_rounds(model):
+    """8195 streams built from 7 distinct ones, 14 frames (the history ring wraps): the front-end kernel's 256 blocks
+    take several grid-stride rounds, the last one ragged.  Identical streams must produce bit-identical features,
+    spectra-derived gains and PCM wherever they sit — catches anything that leaks from one round (or one
+    stream group of a wave) into the next."""
+    B, K, T = 8195, 7, 14
+    base = synth.synth_batch(K, T, first_stream=1)
+    idx = np.arange(B) % K
+    pcm = base[idx]
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    for t in range(T):
+        frame = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])
+        out = np.empty_like(frame)
+        gr = np.empty((B, 68), np.float32)
+        assert ctx.L.pn_process_host_i16(ctx.h, frame.ctypes.data, out.ctypes.data, gr.ctypes.data) == 0
+        feat, sil = ctx.read_features()
+        for k in range(K):
+            m = idx == k
+            f = feat[m].view(np.uint32)
+            assert (f == f[0]).all(), (t, k, "features")
+            assert (sil[m] == sil[m][0]).all(), (t, k, "silence")
+            g = gr[m].view(np.uint32)
+            assert (g == g[0]).all(), (t, k, "g/r")
+            assert (out[m] == out[m][0]).all(), (t, k, "pcm")
+    ctx.close()
