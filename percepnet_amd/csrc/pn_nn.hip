@@ -953,181 +953,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
   }
 }
 
-// ---- large-batch GRU tile: 256 streams x 64 neurons per block (8 waves) ----------------------------
-// Same algorithm, schedule and numerics as pn_gru_mfma_kernel; the bigger tile halves the L2->LDS
-// operand traffic per FLOP (14 KB instead of 28 KB per 128x32x3-gate unit), which is what limited
-// the 128x32 kernel.  Waves: wm = wave&3 owns rows [64wm, 64wm+64) (two 32-row
-// MFMA tiles), wn = wave>>2 owns neuron tile 2*nb+wn.  acc[rt*4 + {z,r,tmp,h}].
-#define GL_THREADS 512
-#define GL_BM 256
-struct NnSharedL {
-  float A[2][GL_BM][LDT];       // 2 x 36864 B
-  float B[2][6 * 32][LDT];      // 2 x 27648 B   tiles (gate g, half wn) at index 2g + wn
-  float tansig[208];
-};
-
-// One K-tile of MFMAs for the large tile.  PF(q) is a hook after each quarter of the MFMAs; issuing
-// the prefetch there in four slices (pinned with sched_barriers) measured SLOWER (2.06 vs 1.89 ms:
-// the barriers stop hipcc hoisting the next quarter's ds_reads), so the prefetch stays one burst
-// in front of the MFMAs and PF is empty.
-#define PN_MMA_L(NG, AO, As_, Bs_, PF) do {                                                               \
-    const int r_ = lane & 31, kh_ = lane >> 5;                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                        \
-      const float4 a0 = *reinterpret_cast<const float4 *>(&(As_)[64 * wm + r_][q * 8 + kh_ * 4]);          \
-      const float4 a1 = *reinterpret_cast<const float4 *>(&(As_)[64 * wm + 32 + r_][q * 8 + kh_ * 4]);     \
-      float4 bq[NG];                                                                                       \
-      _Pragma("unroll") for (int g = 0; g < NG; g++)                                                       \
-        bq[g] = *reinterpret_cast<const float4 *>(&(Bs_)[(2 * g + wn) * 32 + r_][q * 8 + kh_ * 4]);        \
-      PN_STEP_L(NG, AO, x) PN_STEP_L(NG, AO, y) PN_STEP_L(NG, AO, z) PN_STEP_L(NG, AO, w)                  \
-      PF(q);                                                                                               \
-    }                                                                                                      \
-    pn_mfma_drain();                                                                                       \
-  } while (0)
-#define PN_STEP_L(NG, AO, c)                                                                               \
-    _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                       \
-      acc[AO + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, bq[g].c, acc[AO + g], 0, 0, 0);            \
-      acc[4 + AO + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, bq[g].c, acc[4 + AO + g], 0, 0, 0);    \
-    }
-
-struct PnTileRegsL { float4 a[4]; float4 b[3]; };
-
-__global__ __launch_bounds__(GL_THREADS, 2) void pn_gru_mfma_l_kernel(
-    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
-    float *__restrict__ h_new, int n_rows, int n_mtiles) {
-  __shared__ NnSharedL S;
-  const int NTn = N >> 5, NB2 = N >> 6;         // 32-neuron tiles, 64-neuron blocks
-  int mt, nb;
-  if (!pn_tile_of_block(n_mtiles, NB2, mt, nb)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave & 3, wn = wave >> 2;
-  const int m0 = mt * GL_BM, KTh = N >> 5;
-  const int T1 = KTx, T2 = KTx + KTh, TT = 2 * KTx + KTh;
-  const int col = (2 * nb + wn) * 32 + (lane & 31);
-  if (tid < 201) S.tansig[tid] = tansig[tid];
-
-  floatx16 acc[8];
-  {
-    float bz = b[col]; bz += b[3 * N + col];
-    float br = b[N + col]; br += b[4 * N + col];
-    const float bt = b[5 * N + col];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      acc[0][i] = bz; acc[1][i] = br; acc[2][i] = bt;
-      acc[4][i] = bz; acc[5][i] = br; acc[6][i] = bt;
-    }
-  }
-  PN_PANEL_LOCALS(X);
-  // staging roles of this thread: A float4 #it -> row (tid + 512 it) >> 3; B float4 #j -> tile 2j + (tid >> 8)
-  const int brow = (tid & 255) >> 3, bc = tid & 7, bhalf = tid >> 8;      // tile (gate j, half bhalf)
-  const size_t wtile = (size_t)(2 * nb + bhalf);                           // 32-neuron tile this thread stages
-  PnTileRegsL R0, R1;
-  // prefetch of K-tile gg, split in a scalar setup + four slices q = 0..3 (A float4 #q, B float4 #q)
-  const float *pf_a; int pf_ld, pf_k; const float *pf_w0, *pf_w1, *pf_w2; bool pf_b1, pf_b2;
-#define GL_SETUP(gg) do {                                                                                    \
-    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                               \
-    const bool p1_ = g_ < T1, p2_ = g_ >= T1 && g_ < T2;                                                     \
-    const int kx_ = p1_ ? g_ : (p2_ ? 0 : g_ - T2), kh_ = p2_ ? g_ - T1 : 0;                                 \
-    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                                 \
-    pf_a = p2_ ? h_old : pn_seg_ptr(PN_PANEL_PASS, sg_);                                                     \
-    pf_ld = p2_ ? N : pld; pf_k = p2_ ? kh_ * BK : k0_;                                                      \
-    /* weight tile for gate j of the phase: phase1 j=0,1 -> Wp gates z,r; phase2 j=0..2 -> Up; phase3 j=0 -> Wp gate h */ \
-    pf_w0 = p2_ ? Up + ((size_t)(0 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024                         \
-                : Wp + ((size_t)((p1_ ? 0 : 2) * NTn) + wtile) * KTx * 1024 + (size_t)kx_ * 1024;             \
-    pf_w1 = p2_ ? Up + ((size_t)(1 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024                         \
-                : Wp + ((size_t)(1 * NTn) + wtile) * KTx * 1024 + (size_t)kx_ * 1024;                         \
-    pf_w2 = Up + ((size_t)(2 * NTn) + wtile) * KTh * 1024 + (size_t)kh_ * 1024;                              \
-    pf_b1 = p1_ || p2_; pf_b2 = p2_;                                                                         \
-  } while (0)
-#define GL_SLICE(R, q) do {                                                                                  \
-    const int idx_ = tid + GL_THREADS * (q);                                                                 \
-    (R).a[q] = *reinterpret_cast<const float4 *>(pf_a + (size_t)(m0 + (idx_ >> 3)) * pf_ld + pf_k + 4 * (idx_ & 7)); \
-    if ((q) == 0) (R).b[0] = *reinterpret_cast<const float4 *>(pf_w0 + brow * 32 + 4 * bc);                  \
-    if ((q) == 1 && pf_b1) (R).b[1] = *reinterpret_cast<const float4 *>(pf_w1 + brow * 32 + 4 * bc);         \
-    if ((q) == 2 && pf_b2) (R).b[2] = *reinterpret_cast<const float4 *>(pf_w2 + brow * 32 + 4 * bc);         \
-  } while (0)
-#define GL_FETCH(R, gg) do { GL_SETUP(gg); GL_SLICE(R, 0); GL_SLICE(R, 1); GL_SLICE(R, 2); GL_SLICE(R, 3); } while (0)
-#define PF_NONE(q) do {} while (0)
-#define GL_STASH(R, buf) do {                                                                                \
-    _Pragma("unroll") for (int it = 0; it < 4; it++) {                                                       \
-      const int idx_ = tid + GL_THREADS * it; const int row_ = idx_ >> 3, c_ = idx_ & 7;                     \
-      float *dst_ = &S.A[buf][row_][(c_ >> 1) * 8 + 2 * (c_ & 1)];                                           \
-      *reinterpret_cast<float2 *>(dst_) = make_float2((R).a[it].x, (R).a[it].z);                             \
-      *reinterpret_cast<float2 *>(dst_ + 4) = make_float2((R).a[it].y, (R).a[it].w);                         \
-    }                                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < 3; j++)                                                            \
-      *reinterpret_cast<float4 *>(&S.B[buf][(2 * j + bhalf) * 32 + brow][4 * bc]) = (R).b[j];                \
-  } while (0)
-  R0.b[1] = R0.b[2] = R1.b[1] = R1.b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-  GL_FETCH(R0, 0); GL_FETCH(R1, 1);
-  GL_STASH(R0, 0);
-  __syncthreads();
-#pragma unroll 1
-  for (int g = 0; g < T1; g += 2) {
-    GL_FETCH(R0, g + 2);
-    PN_MMA_L(2, 0, S.A[0], S.B[0], PF_NONE);
-    GL_STASH(R1, 1);
-    __syncthreads();
-    GL_FETCH(R1, g + 3);
-    PN_MMA_L(2, 0, S.A[1], S.B[1], PF_NONE);
-    GL_STASH(R0, 0);
-    __syncthreads();
-  }
-#pragma unroll 1
-  for (int g = T1; g < T2; g += 2) {
-    GL_FETCH(R0, g + 2);
-    PN_MMA_L(3, 0, S.A[0], S.B[0], PF_NONE);
-    GL_STASH(R1, 1);
-    __syncthreads();
-    GL_FETCH(R1, g + 3);
-    PN_MMA_L(3, 0, S.A[1], S.B[1], PF_NONE);
-    GL_STASH(R0, 0);
-    __syncthreads();
-  }
-  {
-    const float bh = b[2 * N + col];
-#pragma unroll
-    for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        acc[4 * rt + 0][i] = pn_sigmoid(acc[4 * rt + 0][i], S.tansig);
-        acc[4 * rt + 1][i] = pn_sigmoid(acc[4 * rt + 1][i], S.tansig);
-        float h = bh;
-        h += acc[4 * rt + 2][i] * acc[4 * rt + 1][i];
-        acc[4 * rt + 3][i] = h;
-      }
-  }
-#pragma unroll 1
-  for (int g = T2; g < TT; g += 2) {
-    GL_FETCH(R0, g + 2);
-    PN_MMA_L(1, 3, S.A[0], S.B[0], PF_NONE);
-    GL_STASH(R1, 1);
-    __syncthreads();
-    GL_FETCH(R1, g + 3);
-    PN_MMA_L(1, 3, S.A[1], S.B[1], PF_NONE);
-    GL_STASH(R0, 0);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 64 * wm + 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < n_rows) {
-        const float hv = pn_act(acc[4 * rt + 3][i], act, S.tansig);
-        const float z = acc[4 * rt + 0][i];
-        const float ho = h_old[(size_t)row * N + col];
-        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
-      }
-    }
-#undef GL_FETCH
-#undef GL_STASH
-#undef GL_SETUP
-#undef GL_SLICE
-#undef PF_NONE
-}
-
 // ---- host: weight packing ---------------------------------------------------------------------
 // W[K][ncols] (reference layout) -> Wp[CT][ceil(K/32)][32 cols][32 k-interleaved], zero padded,
 // CT = ceil(ncols/32) rounded up to a multiple of ct_round (the kernel's column tiles per block).
@@ -1196,15 +1021,6 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
     return;
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
-#ifdef PN_USE_LARGE_GRU_TILE        // measured on MI355X: 2.01 ms vs 1.95 ms for the 128x32 kernel -> off
-  if (n_rows >= 8192) {            // enough 256x64 tiles to fill the chip: the traffic-lean large tile
-    const int n_mt = (n_rows + GL_BM - 1) / GL_BM, NB2 = N / 64;
-    const int grid = 8 * ((n_mt + 7) / 8) * NB2;
-    hipLaunchKernelGGL(pn_gru_mfma_l_kernel, dim3(grid), dim3(GL_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps,
-                       act, tansig, h_new, n_rows, n_mt);
-    return;
-  }
-#endif
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
 #ifdef PN_NN_OLD_PIPE
