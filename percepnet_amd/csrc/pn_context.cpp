@@ -133,6 +133,8 @@ struct pn_ctx {
   DevLayer L[PN_NLAYERS];
   PnTables *tables; float *tansig;
   float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
+  // fp16-operand variant only: shadow copies (2 bytes per element, same indexing) of the buffers the GEMMs read
+  uint16_t *c1ringH, *c2ringH, *c2outH, *gruH[4], *rbH;
   float2 *yring, *Ps;              // yring: [6][B][400] look-ahead spectra (X of frame t = slot (t+1)%6)
   float *eyring;                   // [6][B][36] look-ahead band energies
   int *last_period, *silence;
@@ -176,6 +178,13 @@ static int zero_state(pn_ctx *c) {
   for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gru[i], 0, 2 * Bp * 512 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * Bp * 128 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->gr, 0, B * 68 * 4, c->stream));
+  if (c->c1ringH) {
+    PN_HIP_CHECK(hipMemsetAsync(c->c1ringH, 0, 5 * Bp * 128 * 2, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->c2ringH, 0, 3 * Bp * 512 * 2, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->c2outH, 0, Bp * 512 * 2, c->stream));
+    for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gruH[i], 0, 2 * Bp * 512 * 2, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->rbH, 0, 2 * Bp * 128 * 2, c->stream));
+  }
   c->t = 0;
   return 0;
 }
@@ -205,6 +214,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
+  c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
 
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
@@ -237,6 +247,13 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * Bp * 512, false);
   DEV_ALLOC(c->rb, 2 * Bp * 128, false);
   DEV_ALLOC(c->gr, B * 68, false);
+  if (nn_mode == PN_NN_MFMA_F16) {
+    DEV_ALLOC(c->c1ringH, 5 * Bp * 128, false);
+    DEV_ALLOC(c->c2ringH, 3 * Bp * 512, false);
+    DEV_ALLOC(c->c2outH, Bp * 512, false);
+    for (int i = 0; i < 4; i++) DEV_ALLOC(c->gruH[i], 2 * Bp * 512, false);
+    DEV_ALLOC(c->rbH, 2 * Bp * 128, false);
+  }
   DEV_ALLOC(c->io_in, B * PN_FRAME, false);
   DEV_ALLOC(c->io_out, B * PN_FRAME, false);
   if (zero_state(c)) goto fail;
@@ -333,6 +350,22 @@ extern "C" int pn_ctx_reset_profile(pn_ctx *c) {
 static PnSegs seg1(const float *p, int ld, int width) { PnSegs s; memset(&s, 0, sizeof(s)); s.p[0] = p; s.ld[0] = ld; s.width[0] = width; s.n = 1; return s; }
 
 // compute_rnn (rnn.cpp:42-81) for all streams; features in c->feat, result in c->gr
+// fp16 shadow of an fp32 activation pointer (same element index in the twin buffer)
+static uint16_t *shadow(pn_ctx *c, const float *p) {
+  const size_t Bp = c->Bp;
+  struct { const float *f; uint16_t *h; size_t n; } m[8] = {
+      {c->c1ring, c->c1ringH, 5 * Bp * 128}, {c->c2ring, c->c2ringH, 3 * Bp * 512}, {c->c2out, c->c2outH, Bp * 512},
+      {c->gru[0], c->gruH[0], 2 * Bp * 512}, {c->gru[1], c->gruH[1], 2 * Bp * 512}, {c->gru[2], c->gruH[2], 2 * Bp * 512},
+      {c->gru[3], c->gruH[3], 2 * Bp * 512}, {c->rb, c->rbH, 2 * Bp * 128}};
+  for (auto &e : m) if (p >= e.f && p < e.f + e.n) return e.h + (p - e.f);
+  return NULL;
+}
+static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
+  PnSegs H = A;
+  for (int j = 0; j < A.n; j++) H.p[j] = reinterpret_cast<const float *>(shadow(c, A.p[j]));
+  return H;
+}
+
 static void launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
   const bool f16 = c->nn_mode == PN_NN_MFMA_F16;
@@ -342,17 +375,17 @@ static void launch_rnn(pn_ctx *c) {
   float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512;
   { Scope sc(c, KF_FC);
     PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
-    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B);
+    if (f16) pn_launch_dense_f16(st, A, 0, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, shadow(c, c1new), 128, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B); }
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B);
+    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B);
+    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B); }
   const float *x = c->c2out;
   for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
@@ -360,7 +393,7 @@ static void launch_rnn(pn_ctx *c) {
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    if (f16) pn_launch_gru_f16(st, X, ho, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
+    if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
     else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B);
     x = hn;
   }
@@ -371,17 +404,17 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    if (f16) pn_launch_gru_f16(st, X, rbo, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B);
+    if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
     else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B); }
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
+    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B); }
   { Scope sc(c, KF_FC_RB);
     PnSegs A = seg1(rbn, 128, 128);
-    if (f16) pn_launch_dense_f16(st, A, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
+    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, NULL, 0, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B); }
 }
 

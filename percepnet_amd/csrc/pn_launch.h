@@ -20,10 +20,13 @@ size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
 void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
 size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);
 void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);
-void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                         const float *tansig, float *out, int ldo, int n_rows);
-void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, const float *h_old, const void *Wp, const void *Up,
-                       const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
+// fp16-operand variant: a_half = the A panels are fp16 shadow buffers (pointers carried as float*, ld in halfs);
+// outH / h_newH: fp16 shadow of the output (same indexing as the fp32 one), may be NULL
+void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, int a_half, const void *Wp, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, void *outH, int ldoH, int n_rows);
+void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float *h_old, const void *h_oldH,
+                       const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
+                       float *h_new, void *h_newH, int n_rows);
 int pn_dense_nt(int N);
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows);

@@ -253,50 +253,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
   }
 }
 
-// GRU gates, candidate and blend for the 16 outputs of a lane (nnet.cpp:144,156,161-179; activations vec.h:53-75).
-// Staged so that the table reads of all outputs are in flight together: evaluated one output at a time each of the
-// 48 dependent LDS reads costs its full latency.  row0 = first row of the lane (rows row0 + (i&3) + 8(i>>2)).
-__device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float *ho, float bh, int act,
-                                                const float *tab, float *__restrict__ h_new, int N, int col, int row0,
-                                                int n_rows) {
-  PnTsArg az[16], ar[16];
-  float tz[16], tr[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { az[i] = pn_tansig_arg(.5f * acc[0][i]); ar[i] = pn_tansig_arg(.5f * acc[1][i]); }
-#pragma unroll
-  for (int i = 0; i < 16; i++) { tz[i] = tab[az[i].i]; tr[i] = tab[ar[i].i]; }
-  float z[16], hp[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    z[i] = .5f + .5f * pn_tansig_fin(az[i], tz[i]);                 // sigmoid_approx
-    const float r = .5f + .5f * pn_tansig_fin(ar[i], tr[i]);
-    float h = bh;
-    h += acc[3][i] * r;
-    hp[i] = h + acc[2][i];
-  }
-  if (act == ACT_TANH || act == ACT_SIGMOID) {
-    PnTsArg ah[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) ah[i] = pn_tansig_arg(act == ACT_SIGMOID ? .5f * hp[i] : hp[i]);
-    float th[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) th[i] = tab[ah[i].i];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const float t = pn_tansig_fin(ah[i], th[i]);
-      hp[i] = act == ACT_SIGMOID ? .5f + .5f * t : t;
-    }
-  } else if (act == ACT_RELU) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) hp[i] = hp[i] < 0 ? 0 : hp[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int row = row0 + (i & 3) + 8 * (i >> 2);
-    if (row < n_rows) h_new[(size_t)row * N + col] = z[i] * ho[i] + (1 - z[i]) * hp[i];
-  }
-}
-
 // Three-accumulator K-tile: acc[I0], acc[I1], acc[I2] += A * B[0..2]
 template <int I0, int I1, int I2>
 __device__ __forceinline__ void pn_mma_ktile3(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
@@ -416,7 +372,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
       if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh + ho[i];
     }
 #else
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
+    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
 #endif
   }
 #undef GRU_FETCH
@@ -662,7 +618,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
       if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh + ho[i];
     }
 #else
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
+    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
 #endif
   }
 #ifdef PN_NN_CLOCKS
@@ -839,7 +795,7 @@ __global__ __launch_bounds__(256 * (NG + 1), (NG == 1 ? 4 : 3)) void pn_gru_mfma
 #pragma unroll
     for (int i = 0; i < 16; i++)
       ho[i] = h_old[(size_t)(m0 + BM * grp + 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, N, col, m0 + BM * grp + 32 * cw + 4 * (lane >> 5), n_rows);
+    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + BM * grp + 32 * cw + 4 * (lane >> 5), n_rows);
   }
 #ifdef PN_NN_CLOCKS
   if (tid == 0 && N == 512 && blockIdx.x < 8192) {

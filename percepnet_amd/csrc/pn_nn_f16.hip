@@ -2,9 +2,12 @@
 // variant, tolerance re-stated vs CPU fp32 reference") for gfx950.
 //
 // Same layer graph, tiling, software pipeline and fused epilogues as pn_nn.hip; the only change is
-// the GEMM operands: activations (fp32 in HBM, as in every other mode) are rounded to fp16 (RNE)
-// while they are staged into LDS, weights are pre-packed as fp16, and the products are accumulated
-// in fp32 by v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).  Bias preload, table tanh/sigmoid,
+// the GEMM operands: activations are rounded to fp16 (RNE), weights are pre-packed as fp16, and the
+// products are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).  Every
+// layer's epilogue stores its output twice: fp32 (recurrent state, conv rings as seen by taps, the
+// g/r result) and an fp16 shadow copy with the same indexing, which is what the next layer's GEMM
+// reads (AH = true): half the operand bytes per K-tile and no conversion while staging.  The first
+// layer reads the fp32 features (AH = false) and converts while staging.  Same values either way.  Bias preload, table tanh/sigmoid,
 // GRU gating, state blend and every stored activation stay fp32, and the DSP front/back end is
 // untouched, so the deviation from the CPU reference comes only from the 11-bit operand mantissas
 // (and the hardware's summation order inside a 16-wide MFMA dot).  Tolerance: see
@@ -26,27 +29,54 @@ struct NnSharedH {
   float tansig[208];
 };
 
-struct HTileRegs { float4 a[8]; uint4 b[4]; };
+typedef float fvec4 __attribute__((ext_vector_type(4)));      // plain LLVM vector: stays in registers whatever it is cast from
+template <bool AH> struct HTileRegsT { fvec4 a[8]; uint4 b[4]; };   // AH uses a[0..3]
 
-// A tile: 128 rows x 64 k of a row-major fp32 panel = 8 float4 per thread (16 float4 per row)
-__device__ __forceinline__ void h_load_A(float4 (&ra)[8], const float *__restrict__ p, int ld, int k0, int m0) {
+// A tile of 128 rows x 64 k.  AH = false: row-major fp32 panel, 8 float4 per thread (16 per row), converted to
+// fp16 when stored to LDS.  AH = true: tile-major fp16 shadow panel (the pointer is a _Float16* carried as float*,
+// ld = logical row width), 4 x 16 B per thread (8 per row), copied as is.
+// (the register arrays are passed by reference to an array of the exact size: through a decayed pointer the compiler put
+// them in scratch memory and the prefetch turned into load -> wait -> scratch store)
+template <bool AH>
+__device__ __forceinline__ void h_load_A(fvec4 (&ra)[8], const float *__restrict__ p, int ld, int k0, int m0) {
   const int tid = threadIdx.x;
+  if constexpr (AH) {
+    // shadow buffers are tile-major, [M tile][column tile][128 rows][32 cols]: the 128 x 32 tile a block writes is
+    // one contiguous 8 KB run (row-major would leave every 128-byte line half-written by two different blocks)
+    const _Float16 *ph = reinterpret_cast<const _Float16 *>(p) + ((size_t)(m0 / BM) * (ld >> 5) + (k0 >> 5)) * (BM * 32);
 #pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int idx = tid + NN_THREADS * it;
-    const int row = idx >> 4, c = idx & 15;
-    ra[it] = *reinterpret_cast<const float4 *>(p + (size_t)(m0 + row) * ld + k0 + 4 * c);
+    for (int it = 0; it < 4; it++) {
+      const int idx = tid + NN_THREADS * it;
+      const int row = idx >> 3, c = idx & 7;
+      ra[it] = *reinterpret_cast<const fvec4 *>(ph + (size_t)(c >> 2) * (BM * 32) + row * 32 + 8 * (c & 3));
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = tid + NN_THREADS * it;
+      const int row = idx >> 4, c = idx & 15;
+      ra[it] = *reinterpret_cast<const fvec4 *>(p + (size_t)(m0 + row) * ld + k0 + 4 * c);
+    }
   }
 }
-__device__ __forceinline__ void h_store_A(_Float16 (*As)[HLD], const float4 (&ra)[8]) {
+template <bool AH>
+__device__ __forceinline__ void h_store_A(_Float16 (*As)[HLD], const fvec4 (&ra)[8]) {
   const int tid = threadIdx.x;
+  if constexpr (AH) {
 #pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int idx = tid + NN_THREADS * it;
-    const int row = idx >> 4, c = idx & 15;
-    half4 h;
-    h[0] = (_Float16)ra[it].x; h[1] = (_Float16)ra[it].y; h[2] = (_Float16)ra[it].z; h[3] = (_Float16)ra[it].w;
-    *reinterpret_cast<half4 *>(&As[row][4 * c]) = h;
+    for (int it = 0; it < 4; it++) {
+      const int idx = tid + NN_THREADS * it;
+      *reinterpret_cast<fvec4 *>(&As[idx >> 3][8 * (idx & 7)]) = ra[it];
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = tid + NN_THREADS * it;
+      const int row = idx >> 4, c = idx & 15;
+      half4 h;
+      h[0] = (_Float16)ra[it][0]; h[1] = (_Float16)ra[it][1]; h[2] = (_Float16)ra[it][2]; h[3] = (_Float16)ra[it][3];
+      *reinterpret_cast<half4 *>(&As[row][4 * c]) = h;
+    }
   }
 }
 // one packed 32(col) x 64(k) fp16 weight tile = 4 KB contiguous: 16 B per thread
@@ -78,10 +108,55 @@ __device__ __forceinline__ void h_mma_ktile(const _Float16 (*As)[HLD], const _Fl
   pn_mfma_drain();
 }
 
-template <int NT>
+
+// ---- epilogue through LDS --------------------------------------------------------------------------
+// A lane holds 16 values of one output column in 16 different rows, so storing them directly costs 16 dword (and 16
+// short) store instructions per 32-column tile; with K loops this short (12 MFMAs of 32 cycles per K-tile) the stores
+// would dominate — a VMEM instruction costs the issuing wave ~80-100 cycles whatever its width.  The tile goes
+// through LDS instead and leaves as 16-byte stores: 4 per thread for the fp32 rows, 2 for the tile-major fp16 shadow.
+struct alignas(16) HStage { float f[BM][32]; _Float16 h[BM][32]; };          // 16 KB + 8 KB, aliases the A/B buffers
+static_assert(sizeof(HStage) <= sizeof(NnSharedH) - sizeof(float) * 208, "stage");
+
+// called by all 256 threads; v[i] = value of (row m0 + 32*wave + (i&3) + 8*(i>>2) + 4*(lane>>5), column col0 + (lane&31))
+__device__ __forceinline__ void h_store_tile(HStage &T, const float (&v)[16], float *__restrict__ out, int ldo,
+                                             _Float16 *__restrict__ outH_tile, int m0, int col0, int n_rows, int n_cols) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __syncthreads();                                     // every wave is done with the LDS contents being replaced
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int r = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    T.f[r][lane & 31] = v[i];
+    T.h[r][lane & 31] = (_Float16)v[i];
+  }
+  __syncthreads();
+  if (col0 + 32 <= n_cols && (ldo & 3) == 0) {          // whole tile inside the output: 16-byte row segments
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int idx = tid + NN_THREADS * j, r = idx >> 3, c = idx & 7;
+      if (m0 + r < n_rows)
+        *reinterpret_cast<float4 *>(out + (size_t)(m0 + r) * ldo + col0 + 4 * c) = *reinterpret_cast<const float4 *>(&T.f[r][4 * c]);
+    }
+  } else {                                              // ragged last column tile (the 34-wide outputs)
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int idx = tid + NN_THREADS * j, r = idx >> 5, c = idx & 31;
+      if (m0 + r < n_rows && col0 + c < n_cols) out[(size_t)(m0 + r) * ldo + col0 + c] = T.f[r][c];
+    }
+  }
+  if (outH_tile) {                                      // 8 KB contiguous; rows past n_rows are padding rows of the buffer
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int idx = tid + NN_THREADS * j;
+      reinterpret_cast<float4 *>(outH_tile)[idx] = reinterpret_cast<const float4 *>(&T.h[0][0])[idx];
+    }
+  }
+}
+
+template <int NT, bool AH>
 __global__ __launch_bounds__(NN_THREADS) void pn_dense_f16_kernel(
     PnSegs A, const _Float16 *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
-    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, _Float16 *__restrict__ outH, int ldoH,
+    int n_rows, int n_mtiles, int n_cblocks) {
   __shared__ NnSharedH S;
   int mt, cb;
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
@@ -98,15 +173,15 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_f16_kernel(
   }
   const _Float16 *wbase = Wp + (size_t)(cb * NT) * KT * 2048;
   PN_PANEL_LOCALS(A);
-  HTileRegs R0, R1;
+  HTileRegsT<AH> R0, R1;
 #define HD_FETCH(R, gg) do {                                                                   \
     int g_ = (gg); g_ = g_ < KT ? g_ : KT - 1;                                                 \
     const int sg_ = g_ / tps, k0_ = (g_ - sg_ * tps) * HK;                                     \
-    h_load_A((R).a, pn_seg_ptr(PN_PANEL_PASS, sg_), pld, k0_, m0);                             \
+    h_load_A<AH>((R).a, pn_seg_ptr(PN_PANEL_PASS, sg_), pld, k0_, m0);                         \
     _Pragma("unroll") for (int t = 0; t < NT; t++) (R).b[t] = h_load_B(wbase + ((size_t)t * KT + g_) * 2048); \
   } while (0)
 #define HD_STASH(R, buf) do {                                                                  \
-    h_store_A(S.A[buf], (R).a);                                                                \
+    h_store_A<AH>(S.A[buf], (R).a);                                                            \
     _Pragma("unroll") for (int t = 0; t < NT; t++) h_store_B(&S.B[buf][32 * t], (R).b[t]);     \
   } while (0)
   HD_FETCH(R0, 0); HD_FETCH(R1, 1);
@@ -127,22 +202,26 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_f16_kernel(
   }
 #undef HD_FETCH
 #undef HD_STASH
+  HStage &T = *reinterpret_cast<HStage *>(&S.A[0][0][0]);
+  float tab_local = 0; (void)tab_local;
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    const int col = (cb * NT + t) * 32 + (lane & 31);
+    const int col0 = (cb * NT + t) * 32;
+    if (col0 >= N) break;                               // padding column tiles of the 34-wide layers (uniform)
+    float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < n_rows && col < N) out[(size_t)row * ldo + col] = pn_act(acc[t][i], act, S.tansig);
-    }
+    for (int i = 0; i < 16; i++) v[i] = pn_act(acc[t][i], act, S.tansig);
+    _Float16 *tileH = outH ? outH + ((size_t)mt * (ldoH >> 5) + (col0 >> 5)) * (BM * 32) : nullptr;
+    h_store_tile(T, v, out, ldo, tileH, m0, col0, n_rows, N);
   }
 }
 
 // GRU step, acc[0..3] = z, r, hx, tmp; schedule as in pn_gru_mfma_kernel (x tiles then h tiles)
+template <bool AH>
 __global__ __launch_bounds__(NN_THREADS) void pn_gru_f16_kernel(
-    PnSegs X, const float *__restrict__ h_old, const _Float16 *__restrict__ Wp, const _Float16 *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
-    float *__restrict__ h_new, int n_rows, int n_mtiles) {
+    PnSegs X, const float *__restrict__ h_old, const _Float16 *__restrict__ h_oldH, const _Float16 *__restrict__ Wp,
+    const _Float16 *__restrict__ Up, const float *__restrict__ b, int N, int KTx, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ h_new, _Float16 *__restrict__ h_newH, int n_rows, int n_mtiles) {
   __shared__ NnSharedH S;
   const int NTn = N >> 5;
   int mt, nt;
@@ -165,19 +244,20 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_f16_kernel(
   const _Float16 *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 2048, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 2048,
                  *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 2048;
   PN_PANEL_LOCALS(X);
-  HTileRegs R0, R1;
+  HTileRegsT<AH> R0, R1;
+  const float *hA = AH ? reinterpret_cast<const float *>(h_oldH) : h_old;      // recurrent GEMM operand
 #define HG_FETCH(R, gg) do {                                                                               \
     int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
     const bool p1_ = g_ < T1;                                                                              \
     const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * HK;                                               \
-    h_load_A((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old, p1_ ? pld : N, p1_ ? k0_ : kh_ * HK, m0); \
+    h_load_A<AH>((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : hA, p1_ ? pld : N, p1_ ? k0_ : kh_ * HK, m0); \
     (R).b[0] = h_load_B(p1_ ? Wz + (size_t)kx_ * 2048 : Uz + (size_t)kh_ * 2048);                          \
     (R).b[1] = h_load_B(p1_ ? Wr + (size_t)kx_ * 2048 : Ur + (size_t)kh_ * 2048);                          \
     (R).b[2] = h_load_B(p1_ ? Wh + (size_t)kx_ * 2048 : Uh + (size_t)kh_ * 2048);                          \
   } while (0)
 #define HG_STASH(R, buf) do {                                                                              \
-    h_store_A(S.A[buf], (R).a);                                                                            \
+    h_store_A<AH>(S.A[buf], (R).a);                                                                        \
     h_store_B(&S.B[buf][0], (R).b[0]); h_store_B(&S.B[buf][32], (R).b[1]); h_store_B(&S.B[buf][64], (R).b[2]); \
   } while (0)
   HG_FETCH(R0, 0); HG_FETCH(R1, 1);
@@ -209,20 +289,23 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_f16_kernel(
 #undef HG_STASH
   {
     const float bh = b[2 * N + col];
+    float ho[16], v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    for (int i = 0; i < 16; i++)
+      ho[i] = h_old[(size_t)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                       // nnet.cpp:144,156,161-179
       const float z = pn_sigmoid(acc[0][i], S.tansig);
       const float r = pn_sigmoid(acc[1][i], S.tansig);
       float h = bh;
       h += acc[3][i] * r;
       h = h + acc[2][i];
       const float hv = pn_act(h, act, S.tansig);
-      if (row < n_rows) {
-        const float ho = h_old[(size_t)row * N + col];
-        h_new[(size_t)row * N + col] = z * ho + (1 - z) * hv;
-      }
+      v[i] = z * ho[i] + (1 - z) * hv;
     }
+    HStage &T = *reinterpret_cast<HStage *>(&S.A[0][0][0]);
+    _Float16 *tileH = h_newH ? h_newH + ((size_t)mt * (N >> 5) + nt) * (BM * 32) : nullptr;
+    h_store_tile(T, v, h_new, N, tileH, m0, nt * 32, n_rows, N);
   }
 }
 
@@ -250,26 +333,35 @@ void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_r
 
 int pn_dense_nt(int N);   // pn_nn.hip
 
-void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                         const float *tansig, float *out, int ldo, int n_rows) {
+// a_half: the panels of A are fp16 shadow buffers (pointers carried as float*, ld in halfs); outH (optional): fp16
+// shadow of the output with row stride ldoH
+void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, int a_half, const void *Wp, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, void *outH, int ldoH, int n_rows) {
   const int tps = (A.width[0] + HK - 1) / HK, KT = tps * A.n;   // equal-width panels, multiples of 64
   const int NT = pn_dense_nt(N);
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int n_cblocks = h_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
-  if (NT == 4)
-    hipLaunchKernelGGL(pn_dense_f16_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, (const _Float16 *)Wp, bias, N,
-                       KT, tps, act, tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-  else
-    hipLaunchKernelGGL(pn_dense_f16_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, (const _Float16 *)Wp, bias, N,
-                       KT, tps, act, tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+#define HD_LAUNCH(NT_, AH_)                                                                                       \
+  hipLaunchKernelGGL((pn_dense_f16_kernel<NT_, AH_>), dim3(grid), dim3(NN_THREADS), 0, st, A, (const _Float16 *)Wp,  \
+                     bias, N, KT, tps, act, tansig, out, ldo, (_Float16 *)outH, ldoH, n_rows, n_mtiles, n_cblocks)
+  if (NT == 4) { if (a_half) HD_LAUNCH(4, true); else HD_LAUNCH(4, false); }
+  else { if (a_half) HD_LAUNCH(2, true); else HD_LAUNCH(2, false); }
+#undef HD_LAUNCH
 }
 
-void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, const float *h_old, const void *Wp, const void *Up,
-                       const float *b, int N, int act, const float *tansig, float *h_new, int n_rows) {
+void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float *h_old, const void *h_oldH,
+                       const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
+                       float *h_new, void *h_newH, int n_rows) {
   const int tps = (X.width[0] + HK - 1) / HK, KTx = tps * X.n;
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-  hipLaunchKernelGGL(pn_gru_f16_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const _Float16 *)Wp,
-                     (const _Float16 *)Up, b, N, KTx, tps, act, tansig, h_new, n_rows, n_mtiles);
+  if (a_half)
+    hipLaunchKernelGGL(pn_gru_f16_kernel<true>, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const _Float16 *)h_oldH,
+                       (const _Float16 *)Wp, (const _Float16 *)Up, b, N, KTx, tps, act, tansig, h_new,
+                       (_Float16 *)h_newH, n_rows, n_mtiles);
+  else
+    hipLaunchKernelGGL(pn_gru_f16_kernel<false>, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const _Float16 *)h_oldH,
+                       (const _Float16 *)Wp, (const _Float16 *)Up, b, N, KTx, tps, act, tansig, h_new,
+                       (_Float16 *)h_newH, n_rows, n_mtiles);
 }
