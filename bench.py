@@ -174,8 +174,10 @@ def main():
     out = torch.empty((B, FRAME), dtype=torch.int16, device=dev)
     del pool
 
+    gr_buf = torch.empty((B, 68), dtype=torch.float32, device=dev) if os.environ.get("PN_BENCH_GR") else None
+
     def step(t):
-        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
+        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), gr_buf.data_ptr() if gr_buf is not None else None)
 
     print(f"[bench] inputs resident ({T} frames x {B} streams), state {ctx.device_bytes() / 2**30:.2f} GiB",
           file=sys.stderr, flush=True)
@@ -201,6 +203,9 @@ def main():
 
     kt = {} if a.no_profile else ctx.kernel_times()
     checksum = int(out.to(torch.int64).abs().sum().item())     # keeps the result live / sanity
+    if os.environ.get("PN_BENCH_DUMP"):                         # debugging aid: last frame's PCM of this rank
+        import numpy as _np
+        _np.save(os.environ["PN_BENCH_DUMP"], out.cpu().numpy())
 
     if rank == 0:
         res = {

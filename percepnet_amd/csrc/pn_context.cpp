@@ -146,10 +146,15 @@ struct pn_ctx {
 };
 
 static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
-  PN_HIP_CHECK(hipMalloc(p, bytes));
+  // PERCEPNET_GUARD=1 (debugging aid): every buffer is followed by 1 MB of 0xFF (NaN as fp32 and as fp16), so that a
+  // read past the end of a buffer shows up as NaN in the outputs instead of as run-to-run noise
+  static const bool guard = getenv("PERCEPNET_GUARD") != NULL;
+  const size_t pad = guard ? (1u << 20) : 0, body = (bytes + 255) & ~(size_t)255;
+  PN_HIP_CHECK(hipMalloc(p, guard ? body + pad : bytes));
   c->allocs.push_back(*p);
   c->bytes += bytes;
   if (zero) PN_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, c->stream));
+  if (guard) PN_HIP_CHECK(hipMemsetAsync((char *)*p + body, 0xFF, pad, c->stream));
   return 0;
 }
 #define DEV_ALLOC(ptr, count, zero) \
@@ -314,7 +319,12 @@ struct Scope {
   Scope(pn_ctx *c_, int fam_) : c(c_), fam(fam_), on(c_->profiling) {
     if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
   }
-  ~Scope() { if (on) { hipEventRecord(b, c->stream); c->events.push_back({fam, a, b}); } }
+  ~Scope() {
+    if (on) { hipEventRecord(b, c->stream); c->events.push_back({fam, a, b}); }
+    // debugging aid: PERCEPNET_SYNC_EACH=<bit mask over kernel families, -1 = all>: host sync after those launches
+    static const long sync_mask = getenv("PERCEPNET_SYNC_EACH") ? strtol(getenv("PERCEPNET_SYNC_EACH"), NULL, 0) : 0;
+    if (sync_mask & (1L << fam)) hipStreamSynchronize(c->stream);
+  }
 };
 
 static int flush_events(pn_ctx *c) {

@@ -1,0 +1,34 @@
+"""Cross-process determinism: each invocation processes T frames (fresh process, fresh device memory), saves g/r of every frame
+under gpurun_out/ and compares with the previous invocation's file if present."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from percepnet_amd import api, synth, weights
+B = int(sys.argv[1]); T = int(sys.argv[2]); mode = {"f32": api.NN_MFMA, "f16": api.NN_MFMA_F16}[sys.argv[3]]
+dev = torch.device("cuda:0")
+junk = torch.full((1 << 28,), float("nan"), device=dev) if len(sys.argv) > 4 else None     # poison free memory first
+del junk
+model = api.Model(weights.default_blob(1234))
+P = min(B, 64)
+pool = torch.from_numpy(synth.synth_batch(P, T)).to(dev)
+idx = torch.arange(B, device=dev) % P
+rot = (torch.arange(B, device=dev) // P) * 37
+ar = (torch.arange(480, device=dev)[None, :] + rot[:, None]) % 480
+frames = [torch.gather(pool[:, t*480:(t+1)*480][idx], 1, ar).contiguous() for t in range(T)]
+ctx = api.Context(model, B, nn_mode=mode, stream=torch.cuda.current_stream().cuda_stream)
+out = torch.empty((B, 480), dtype=torch.int16, device=dev); gr = torch.empty((T, B, 68), dtype=torch.float32, device=dev)
+for t in range(T):
+    ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), gr[t].data_ptr())
+torch.cuda.synchronize()
+g = gr.cpu().numpy()
+f = f"gpurun_out/xproc_{sys.argv[3]}_{B}.npy"
+os.makedirs("gpurun_out", exist_ok=True)
+if os.path.exists(f):
+    g0 = np.load(f)
+    d = np.argwhere(g.view(np.uint32) != g0.view(np.uint32))
+    print(f"{sys.argv[3]} B={B} T={T}: identical to previous process = {len(d) == 0}; nan count {np.isnan(g).sum()}")
+    if len(d):
+        print("  first (frame, stream, col):", d[:5].tolist(), "count", len(d), "frames", np.unique(d[:, 0])[:8].tolist(), "max|d|", float(np.nanmax(np.abs(g - g0))))
+else:
+    print("saved baseline; nan count", np.isnan(g).sum())
+np.save(f, g)
