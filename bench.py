@@ -179,6 +179,10 @@ def main():
     def step(t):
         ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), gr_buf.data_ptr() if gr_buf is not None else None)
 
+    # The context runs on its own non-blocking HIP stream, the inputs above were produced by torch kernels on torch's
+    # stream: without this the warm-up frames can be read while their last rows are still being written
+    # (run-to-run noise in the last few thousand streams; seen with the faster fp16 variant).
+    torch.cuda.synchronize()
     print(f"[bench] inputs resident ({T} frames x {B} streams), state {ctx.device_bytes() / 2**30:.2f} GiB",
           file=sys.stderr, flush=True)
     for t in range(W):

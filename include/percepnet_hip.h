@@ -75,7 +75,12 @@ size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state +
    [n_streams][68] = g[34] | r[34], the reference's feature_test.raw tap (denoise.cpp:533-534).
    f32 = the rnnoise_process_frame sample convention (nominal [-1,1));
    i16 = the CLI convention (main.cpp:34,36): in/32768.f, out = trunc(x*32768) wrapped to 16 bit.
-   in and out may alias. */
+   in and out may alias.
+   Ordering is the caller's: the launches only see what is complete on the context's stream.  A
+   context created with hip_stream = NULL runs on its own NON-BLOCKING stream, which does not
+   synchronise with the null stream or with any other stream: buffers filled by another stream
+   (or by hipMemcpyAsync) must be ordered first (hipStreamWaitEvent / a synchronise), and the
+   outputs consumed after pn_ctx_synchronize or an event on that stream. */
 int pn_process_f32(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr);
 int pn_process_i16(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr);
 /* n_frames consecutive frames per call: in/out are [n_frames][n_streams][480] (frame-major). */

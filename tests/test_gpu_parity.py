@@ -226,6 +226,7 @@ def test_full_size_properties_65536_streams(model, oracle):
         fr = torch.from_numpy(base[:, t * 480:(t + 1) * 480][idx]).to(dev)
         o = torch.empty_like(fr)
         g = torch.empty((B, 68), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                # the context runs on its own stream: inputs complete first
         ctx.process_i16_dev(fr.data_ptr(), o.data_ptr(), g.data_ptr())
         torch.cuda.synchronize()
         o = o.cpu().numpy(); g = g.cpu().numpy()

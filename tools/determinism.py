@@ -12,6 +12,7 @@ idx = torch.arange(B, device=dev) % P
 rot = (torch.arange(B, device=dev) // P) * 37          # per-replica sample rotation, as bench.py does: all streams distinct
 ar = (torch.arange(480, device=dev)[None, :] + rot[:, None]) % 480
 frames = [torch.gather(pool[:, t*480:(t+1)*480][idx], 1, ar).contiguous() for t in range(T)]
+torch.cuda.synchronize()      # the context has its own stream: inputs must be complete before it reads them
 res = []
 for rep in range(2):
     ctx = api.Context(model, B, nn_mode=mode, stream=torch.cuda.current_stream().cuda_stream)

@@ -19,6 +19,7 @@ idx = torch.arange(B, device=dev) % P
 rot = (torch.arange(B, device=dev) // P) * 37
 ar = (torch.arange(480, device=dev)[None, :] + rot[:, None]) % 480
 frames = [torch.gather(pool[:, t*480:(t+1)*480][idx], 1, ar).contiguous() for t in range(T)]
+torch.cuda.synchronize()      # the context has its own stream: inputs must be complete before it reads them
 outs = [torch.empty((B, 480), dtype=torch.int16, device=dev) for _ in range(2)]
 Bp = (B + 255) // 256 * 256
 names = {0: ("feat", Bp * 128), 1: ("c1ring", 5 * Bp * 128), 2: ("c2ring", 3 * Bp * 512), 3: ("c2out", Bp * 512),

@@ -15,6 +15,7 @@ P = min(B, 64); T = 8
 pool = torch.from_numpy(synth.synth_batch(P, T)).to(dev)
 idx = torch.arange(B, device=dev) % P
 frames = [pool[:, t*480:(t+1)*480][idx].contiguous() for t in range(T)]
+torch.cuda.synchronize()      # the context has its own stream: inputs must be complete before it reads them
 out = torch.empty((B, 480), dtype=torch.int16, device=dev)
 buf = (ctypes.c_ulonglong * 24)()
 for t in range(T):

@@ -15,6 +15,7 @@ idx = torch.arange(B, device=dev) % P
 rot = (torch.arange(B, device=dev) // P) * 37
 ar = (torch.arange(480, device=dev)[None, :] + rot[:, None]) % 480
 frames = [torch.gather(pool[:, t*480:(t+1)*480][idx], 1, ar).contiguous() for t in range(T)]
+torch.cuda.synchronize()      # the context has its own stream: inputs must be complete before it reads them
 ctx = api.Context(model, B, nn_mode=mode, stream=torch.cuda.current_stream().cuda_stream)
 out = torch.empty((B, 480), dtype=torch.int16, device=dev); gr = torch.empty((T, B, 68), dtype=torch.float32, device=dev)
 for t in range(T):
