@@ -328,16 +328,17 @@ def test_multi_frame_device_api(model, oracle):
     ctx.close()
 
 
-def test_placement_invariance_across_grid_stride_rounds(model):
+@pytest.mark.parametrize("mode", ["mfma", "f16"])
+def test_placement_invariance_across_grid_stride_rounds(model, mode):
     """8195 streams built from 7 distinct ones, 14 frames (the history ring wraps): the front-end kernel's 256 blocks
     take several grid-stride rounds, the last one ragged.  Identical streams must produce bit-identical features,
     spectra-derived gains and PCM wherever they sit — catches anything that leaks from one round (or one
-    stream group of a wave) into the next."""
+    stream group of a wave) into the next.  Holds for the fp16 network variant too (same arithmetic in every tile)."""
     B, K, T = 8195, 7, 14
     base = synth.synth_batch(K, T, first_stream=1)
     idx = np.arange(B) % K
     pcm = base[idx]
-    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA if mode == "mfma" else api.NN_MFMA_F16)
     for t in range(T):
         frame = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])
         out = np.empty_like(frame)
