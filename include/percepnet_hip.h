@@ -83,6 +83,12 @@ size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state +
    outputs consumed after pn_ctx_synchronize or an event on that stream. */
 int pn_process_f32(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr);
 int pn_process_i16(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr);
+/* Optional output stage: the reference's envelope post-filter
+   (post_filtering, denoise.cpp:216-250), which it only runs on train()'s TEST synthesis (743),
+   applied to the gains inside the back-end kernel between the g/r tap and pitch_filter — the same
+   place.  Off by default (= rnnoise_process_frame exactly); the tap keeps the network's raw g.
+   Takes effect from the next frame. */
+int pn_ctx_set_postfilter(pn_ctx *ctx, int enable);
 /* n_frames consecutive frames per call: in/out are [n_frames][n_streams][480] (frame-major). */
 int pn_process_i16_multi(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr, int n_frames);
 /* Host-buffer convenience wrappers (H2D, process, D2H, synchronise). */

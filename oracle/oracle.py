@@ -46,6 +46,7 @@ class Oracle:
         L.pno_destroy.argtypes = [ctypes.c_void_p]
         L.pno_process_frame.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
         L.pno_run_pcm.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, c_s, c_f]
+        L.pno_run_pcm_pf.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, c_s, c_f, ctypes.c_int]
         L.pno_run_float.argtypes = [ctypes.c_void_p, c_f, ctypes.c_int, c_f, c_f]
         L.pno_frame_features.argtypes = [ctypes.c_void_p, c_f, c_f]
         L.pno_frame_features.restype = ctypes.c_int
@@ -62,13 +63,13 @@ class Oracle:
         if blob is not None:
             assert self.model, "bad PNW1 blob"
 
-    def run_pcm(self, pcm, want_gr=True):
+    def run_pcm(self, pcm, want_gr=True, postfilter=False):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
         n = pcm.size // 480
         out = np.zeros(max(n - 1, 0) * 480, np.int16)
         gr = np.zeros((n, 68), np.float32)
-        self.lib.pno_run_pcm(self.model, pcm.ctypes.data_as(c_s), n, out.ctypes.data_as(c_s),
-                             _fp(gr) if want_gr else None)
+        self.lib.pno_run_pcm_pf(self.model, pcm.ctypes.data_as(c_s), n, out.ctypes.data_as(c_s),
+                                _fp(gr) if want_gr else None, int(bool(postfilter)))
         return out, gr
 
     def run_float(self, x):

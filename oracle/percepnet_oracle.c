@@ -543,6 +543,7 @@ struct pno_state {
   float last_gain; int last_period; float pitch_corr;
   float conv1_mem[4 * 128], conv2_mem[2 * 512];
   float gru1[512], gru2[512], gru3[512], gru_gb[512], gru_rb[128];
+  int postfilter;                 /* optional output stage, see pno_set_postfilter */
 };
 
 pno_state *pno_create(const pno_model *m) {
@@ -620,6 +621,14 @@ int pno_frame_features(pno_state *st, const float *in, float *feat70) {
 }
 
 /* rnnoise_process_frame denoise.cpp:508-547 */
+static void post_filtering(float *g, const float *Ey);
+
+/* the reference's envelope post-filter (denoise.cpp:216-250) exists only on train()'s TEST
+   synthesis (call site 743: post_filtering(g, Ey) between the gains and pitch_filter, Ey = band energy of the
+   spectrum being enhanced).  As an optional inference stage it sits at the same place in rnnoise_process_frame:
+   after compute_rnn and the g/r tap (531-534), before pitch_filter (536); the tap keeps the network's raw g. */
+void pno_set_postfilter(pno_state *st, int on) { st->postfilter = on != 0; }
+
 void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68) {
   frame_ana a; float features[70], g[NB], r[NB], gf[FREQ], rf[FREQ], inv_r[NB];
   cpx x[WINDOW], y[WINDOW]; float t[WINDOW]; int i;
@@ -627,6 +636,7 @@ void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68) 
   make_features(st, &a, features);
   pno_compute_rnn(st, g, r, features);
   if (gr68) { memcpy(gr68, g, sizeof(g)); memcpy(gr68 + NB, r, sizeof(r)); }
+  if (st->postfilter) post_filtering(g, a.Ex);
   if (!a.silence) {                                          /* pitch_filter 436-485 */
     for (i = 0; i < FREQ; i++) rf[i] = 0;
     for (i = 0; i < NB; i++) inv_r[i] = 1 - r[i];
@@ -659,7 +669,11 @@ static short f2s(float v) {
 
 /* main.cpp:30-39 */
 void pno_run_pcm(const pno_model *m, const short *pcm_in, int n_frames, short *pcm_out, float *gr) {
+  pno_run_pcm_pf(m, pcm_in, n_frames, pcm_out, gr, 0);
+}
+void pno_run_pcm_pf(const pno_model *m, const short *pcm_in, int n_frames, short *pcm_out, float *gr, int postfilter) {
   pno_state *st = pno_create(m); float x[FRAME]; int t, i;
+  pno_set_postfilter(st, postfilter);
   for (t = 0; t < n_frames; t++) {
     for (i = 0; i < FRAME; i++) x[i] = ((float)pcm_in[(size_t)t * FRAME + i]) / 32768.f;
     pno_process_frame(st, x, x, gr ? gr + (size_t)t * 68 : NULL);

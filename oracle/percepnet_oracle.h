@@ -34,6 +34,9 @@ void pno_destroy(pno_state *st);
 void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68);
 /* the percepNet_run loop on in-memory PCM (first output frame dropped) */
 void pno_run_pcm(const pno_model *m, const short *pcm_in, int n_frames, short *pcm_out, float *gr);
+/* optional envelope post-filter (denoise.cpp:216-250) between the g/r tap and pitch_filter */
+void pno_set_postfilter(pno_state *st, int on);
+void pno_run_pcm_pf(const pno_model *m, const short *pcm_in, int n_frames, short *pcm_out, float *gr, int postfilter);
 void pno_run_float(const pno_model *m, const float *in, int n_frames, float *out, float *gr);
 
 /* ---- stage functions (exported for per-stage parity tests) ---- */

@@ -57,6 +57,7 @@ def load_library():
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
     L.pn_ctx_synchronize.argtypes = [_vp]
+    L.pn_ctx_set_postfilter.argtypes = [_vp, ctypes.c_int]
     L.pn_ctx_read_features.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_compute_rnn_host.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_set_profiling.argtypes = [_vp, ctypes.c_int]
@@ -134,6 +135,10 @@ class Context:
 
     def synchronize(self):
         self._chk(self.L.pn_ctx_synchronize(self.h))
+
+    def set_postfilter(self, enable):
+        """Optional envelope post-filter on the gains (reference post_filtering, denoise.cpp:216-250)."""
+        self._chk(self.L.pn_ctx_set_postfilter(self.h, int(bool(enable))))
 
     def device_bytes(self):
         return self.L.pn_ctx_device_bytes(self.h)

@@ -15,16 +15,17 @@ extern const RNNModel percepnet_model_orig __attribute__((weak));
 
 int main(int argc, char **argv) {
   const char *model_path = getenv("PERCEPNET_MODEL");
-  int strict = 0, device = 0, ai = 1;
+  int strict = 0, device = 0, postfilter = 0, ai = 1;
   for (; ai < argc; ai++) {
     if (!strcmp(argv[ai], "--model") && ai + 1 < argc) model_path = argv[++ai];
     else if (!strcmp(argv[ai], "--strict")) strict = 1;
+    else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
     else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) device = atoi(argv[++ai]);
     else break;
   }
   const int nfiles = argc - ai;
   if (nfiles < 2 || (nfiles & 1)) {
-    fprintf(stderr, "usage: %s [--model model.pnw] [--strict] [--device N] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
+    fprintf(stderr, "usage: %s [--model model.pnw] [--strict] [--postfilter] [--device N] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
     return 1;
   }
   const int B = nfiles / 2;
@@ -34,6 +35,7 @@ int main(int argc, char **argv) {
   if (!m) { fprintf(stderr, "no model: pass --model file.pnw (or link a generated nnet_data.cpp): %s\n", pn_last_error()); return 2; }
   pn_ctx *cx = pn_ctx_create(m, device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
   if (!cx) { fprintf(stderr, "pn_ctx_create: %s\n", pn_last_error()); return 3; }
+  if (postfilter) pn_ctx_set_postfilter(cx, 1);
   std::vector<FILE *> fin(B), fout(B);
   for (int s = 0; s < B; s++) {
     fin[s] = fopen(argv[ai + 2 * s], "rb"); fout[s] = fopen(argv[ai + 2 * s + 1], "wb");

@@ -137,6 +137,7 @@ struct pn_ctx {
   uint16_t *c1ringH, *c2ringH, *c2outH, *gruH[4], *rbH;
   float2 *yring, *Ps;              // yring: [6][B][400] look-ahead spectra (X of frame t = slot (t+1)%6)
   float *eyring;                   // [6][B][36] look-ahead band energies
+  bool postfilter = false;         // optional envelope post-filter in the back end (pn_ctx_set_postfilter)
   int *last_period, *silence;
   std::vector<void *> allocs;
   bool profiling;
@@ -437,11 +438,19 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
     // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6
-    const float2 *Xs = c->yring + (size_t)((c->t + 1) % 6) * c->B * PN_SPEC_BINS;
-    pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, c->silence, c->synth, d_out, is_i16); }
+    const size_t slot = (size_t)((c->t + 1) % 6);
+    const float2 *Xs = c->yring + slot * c->B * PN_SPEC_BINS;
+    const float *Ex = c->postfilter ? c->eyring + slot * c->B * 36 : nullptr;      // Ex(t) = Ey_lookahead(t-5)
+    pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, Ex, c->silence, c->synth, d_out, is_i16); }
   if (d_gr) PN_HIP_CHECK(hipMemcpyAsync(d_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToDevice, c->stream));
   PN_HIP_CHECK(hipGetLastError());
   c->t++;
+  return 0;
+}
+
+extern "C" int pn_ctx_set_postfilter(pn_ctx *c, int enable) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  c->postfilter = enable != 0;
   return 0;
 }
 

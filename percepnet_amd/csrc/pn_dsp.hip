@@ -163,11 +163,14 @@ __device__ __forceinline__ int16_t pn_f2s(float v) {
   return (int16_t)(uint16_t)((uint32_t)t & 0xffffu);
 }
 
-template <typename TOut>
+// PF: optional envelope post-filter (reference post_filtering, denoise.cpp:216-250) on the
+// gains before pitch_filter and the gain stage, where the reference's TEST synthesis has it (743).
+template <typename TOut, bool PF>
 __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend_kernel(
     const PnTables *__restrict__ T, int n_streams,
     const float2 *__restrict__ Xspec, const float2 *__restrict__ Pspec,
     const float *__restrict__ gr,          // [n_streams][68]  g | r
+    const float *__restrict__ ex,          // PF only: [n_streams][36] band energies of Xspec
     const int *__restrict__ silence,
     float *__restrict__ synth_mem,         // [n_streams][480]
     TOut *__restrict__ out) {              // [n_streams][480]
@@ -190,8 +193,30 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
     if (lane < PN_NB) {
       const float g = gr[(size_t)s * 68 + lane], r = gr[(size_t)s * 68 + PN_NB + lane];
       W.e[0][lane] = g; W.e[1][lane] = r; W.e[2][lane] = 1 - r;
+      if (PF) W.e[3][lane] = ex[(size_t)s * 36 + lane];
     }
     PN_WAVE_SYNC();
+    if (PF) {
+      // warped gain g*sinf(pi/2*g) (the pi/2*g product is double, 227), two sequential float sums in band
+      // order (231-238), one global factor (241-244).  Every lane runs the 34-term chains redundantly on
+      // LDS broadcasts; sinf is OCML's here and libm's in the reference (both within 1 ULP of sin).
+      float gw = 0.f;
+      float *gws = reinterpret_cast<float *>(W.fft);          // the FFT buffer is free until the scatter below
+      if (lane < PN_NB) { const float g = W.e[0][lane]; gw = g * sinf((float)(M_PI / 2 * (double)g)); gws[lane] = gw; }
+      PN_WAVE_SYNC();
+      float E0 = 0.f, E1 = 0.f;
+#pragma unroll 2
+      for (int i = 0; i < PN_NB; i++) {
+        const float e = W.e[3][i];
+        E0 += W.e[0][i] * e;
+        E1 += gws[i] * e;
+      }
+      const float E_div = E0 / (E1 + 1e-6f);
+      const float G = sqrtf(((1 + 0.02f) * E_div) / (1 + 0.02f * (E_div * E_div)));
+      PN_WAVE_SYNC();
+      if (lane < PN_NB) W.e[0][lane] = G * gw;
+      PN_WAVE_SYNC();
+    }
     // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian
     // extension + scale + digit-reverse scatter of inverse_transform (306-317).  Bins >= 400
     // are exactly 0 (interp_band_gain never writes them).
@@ -268,12 +293,23 @@ static inline int pn_dsp_grid(int n_streams, int blocks_per_cu) {
 }
 
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
-                       const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16) {
+                       const float *gr, const float *ex_postfilter, const int *silence, float *synth_mem, void *out,
+                       int out_is_i16) {
   const int grid = pn_dsp_grid(n_streams, 0);
-  if (out_is_i16)
-    hipLaunchKernelGGL(pn_backend_kernel<int16_t>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, Xs, Ps, gr, silence,
-                       synth_mem, (int16_t *)out);
-  else
-    hipLaunchKernelGGL(pn_backend_kernel<float>, dim3(grid), dim3(DSP_THREADS), 0, st, T, n_streams, Xs, Ps, gr, silence,
-                       synth_mem, (float *)out);
+  const dim3 g(grid), b(DSP_THREADS);
+  if (ex_postfilter) {
+    if (out_is_i16)
+      hipLaunchKernelGGL((pn_backend_kernel<int16_t, true>), g, b, 0, st, T, n_streams, Xs, Ps, gr, ex_postfilter, silence,
+                         synth_mem, (int16_t *)out);
+    else
+      hipLaunchKernelGGL((pn_backend_kernel<float, true>), g, b, 0, st, T, n_streams, Xs, Ps, gr, ex_postfilter, silence,
+                         synth_mem, (float *)out);
+  } else {
+    if (out_is_i16)
+      hipLaunchKernelGGL((pn_backend_kernel<int16_t, false>), g, b, 0, st, T, n_streams, Xs, Ps, gr, ex_postfilter, silence,
+                         synth_mem, (int16_t *)out);
+    else
+      hipLaunchKernelGGL((pn_backend_kernel<float, false>), g, b, 0, st, T, n_streams, Xs, Ps, gr, ex_postfilter, silence,
+                         synth_mem, (float *)out);
+  }
 }

@@ -132,7 +132,7 @@ static int fg_frame(pn_featgen *c, const int16_t *sp, const int16_t *no, long lo
                     c->noisy.aux, c->noisy.last_period, rec, rec_stride, c->gr);
   // the synthesis memory must advance every frame whether or not the caller keeps the PCM (753)
   pn_launch_backend(c->stream, c->tables, c->B, c->noisy.yring + (size_t)slot_r * B * PN_SPEC_BINS, c->noisy.Ps, c->gr,
-                    c->noisy.silence, c->synth, c->tmp_out, 0);
+                    nullptr /* the targets kernel already post-filtered g (743) */, c->noisy.silence, c->synth, c->tmp_out, 0);
   if (pcm) pn_launch_saturate_i16(c->stream, c->B, c->tmp_out, pcm, pcm_stride);
   PN_HIP_CHECK(hipGetLastError());
   c->t++;

@@ -15,7 +15,8 @@ void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const flo
                        const int *period_noisy, float *records, long long rec_stride, float *gr);
 void pn_launch_saturate_i16(hipStream_t st, int n_pairs, const float *in, int16_t *out, long long out_stride);
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
-                       const float *gr, const int *silence, float *synth_mem, void *out, int out_is_i16);
+                       const float *gr, const float *ex_postfilter /* NULL = off */, const int *silence, float *synth_mem,
+                       void *out, int out_is_i16);
 size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
 void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
 size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);

@@ -53,6 +53,31 @@ def test_strict_mode_bit_exact_pcm_and_taps(model, oracle):
     ctx.close()
 
 
+def test_postfilter_option(model, oracle):
+    """the optional envelope post-filter (reference post_filtering, denoise.cpp:216-250) between
+    the g/r tap and pitch_filter.  The network and its tap are untouched (bit-identical, STRICT); the PCM follows the
+    oracle's post-filtered output within 1 LSB — the warped gain uses sinf, libm's on the CPU and OCML's on the GPU,
+    both within 1 ULP of sin but not of each other — and really differs from the unfiltered output.  Switching the
+    stage off again gives back the plain pipeline from the next frame (the synthesis overlap carries one frame)."""
+    B, T = 8, 40
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    ctx.set_postfilter(True)
+    out, gr = ctx.run_pcm(pcm)
+    ro = np.stack([oracle.run_pcm(pcm[s], postfilter=True)[0] for s in range(B)])
+    plain, rg = _oracle_batch(oracle, pcm)
+    assert np.array_equal(gr, rg)
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    assert d.max() <= PCM_TOL_LSB, d.max()
+    assert (d != 0).mean() < 0.01
+    assert np.abs(ro.astype(np.int32) - plain.astype(np.int32)).max() > 50      # the stage does something
+    ctx.set_postfilter(False)
+    ctx.reset()
+    out2, _ = ctx.run_pcm(pcm)
+    assert np.array_equal(out2, plain)
+    ctx.close()
+
+
 def test_golden_vectors_strict(model, golden_dir):
     """The committed outputs of the compiled reference (tests/golden/make_golden.py)."""
     g = np.load(os.path.join(golden_dir, "pcm_golden.npz"))

@@ -72,6 +72,21 @@ def test_oracle_matches_golden_pcm(oracle, golden_dir):
     assert 0 < sil.sum() < sil.size
 
 
+def test_oracle_postfilter_option(oracle):
+    """Optional envelope post-filter: off = the plain pipeline; on = same network tap, different
+    PCM.  post_filtering itself is the function the train() restatement uses, pinned by the train parity tests below."""
+    pcm = synth.synth_stream(3, 30)
+    o0, g0 = oracle.run_pcm(pcm)
+    o0b, _ = oracle.run_pcm(pcm, postfilter=False)
+    o1, g1 = oracle.run_pcm(pcm, postfilter=True)
+    assert np.array_equal(o0, o0b)
+    assert np.array_equal(g0.view(np.uint32), g1.view(np.uint32))
+    assert np.abs(o0.astype(np.int32) - o1.astype(np.int32)).max() > 50
+    # warped gains are never larger than the gains (sin <= 1) and the compensation G is bounded by
+    # sqrt((1+beta)/(2*sqrt(beta))) for beta = 0.02: the filtered output stays finite and of comparable level
+    assert np.abs(o1.astype(np.int32)).max() < 4 * max(1, np.abs(o0.astype(np.int32)).max())
+
+
 def test_activation_table_edges(oracle):
     L = oracle.lib
     assert L.pno_tansig(0.0) == 0.0
