@@ -94,6 +94,21 @@ int pn_process_i16_multi(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float
 /* Host-buffer convenience wrappers (H2D, process, D2H, synchronise). */
 int pn_process_host_f32(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr);
 int pn_process_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr);
+/* Pipelined host-buffer entry points: the same work as pn_process_host_*, but the call returns
+   once the frame is queued.  Copy-in, the launches and copy-out of consecutive frames overlap on
+   three streams with double-buffered device staging, so a caller feeding frames back to back gets
+   the device rate instead of the serial copy+compute+copy rate.  At most two frames are in
+   flight: the call blocks until the frame submitted two calls earlier has been delivered.
+   Lifetime: h_in must stay unmodified, and h_out / h_gr are undefined, until THAT frame is
+   delivered — after pn_host_wait(ctx), or once the second next pn_submit_host_* call has
+   returned.  Use pinned host memory (pn_host_alloc / hipHostMalloc / hipHostRegister): with
+   pageable memory the runtime stages the copies and nothing overlaps.  Results are identical to
+   pn_process_host_*; the two families may be mixed (the synchronous one drains the pipeline). */
+int pn_submit_host_f32(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr);
+int pn_submit_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr);
+int pn_host_wait(pn_ctx *ctx);               /* every submitted frame delivered */
+void *pn_host_alloc(size_t bytes);           /* pinned host memory (hipHostMalloc); NULL on failure */
+void pn_host_free(void *p);
 int pn_ctx_synchronize(pn_ctx *ctx);
 
 /* Mid-pipeline taps for per-stage parity tests (device -> host copies, synchronising).

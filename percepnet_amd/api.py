@@ -56,6 +56,13 @@ def load_library():
     for name in ("pn_process_f32", "pn_process_i16", "pn_process_host_f32", "pn_process_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
+    for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
+        getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
+    L.pn_host_wait.argtypes = [_vp]
+    L.pn_host_alloc.argtypes = [ctypes.c_size_t]
+    L.pn_host_alloc.restype = _vp
+    L.pn_host_free.argtypes = [_vp]
+    L.pn_host_free.restype = None
     L.pn_ctx_synchronize.argtypes = [_vp]
     L.pn_ctx_set_postfilter.argtypes = [_vp, ctypes.c_int]
     L.pn_ctx_read_features.argtypes = [_vp, _vp, _vp]
@@ -149,6 +156,13 @@ class Context:
 
     def process_f32_dev(self, d_in, d_out, d_gr=None):
         self._chk(self.L.pn_process_f32(self.h, d_in, d_out, d_gr))
+
+    # pipelined host-buffer entry points (raw host pointers; the buffers should be pinned and must outlive delivery)
+    def submit_host_i16(self, h_in, h_out, h_gr=None):
+        self._chk(self.L.pn_submit_host_i16(self.h, h_in, h_out, h_gr))
+
+    def host_wait(self):
+        self._chk(self.L.pn_host_wait(self.h))
 
     # host numpy entry points
     def process_i16(self, frame, want_gr=True):

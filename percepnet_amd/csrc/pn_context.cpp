@@ -144,6 +144,15 @@ struct pn_ctx {
   struct Ev { int fam; hipEvent_t a, b; };
   std::vector<Ev> events;
   double fam_ms[KF_COUNT]; int64_t fam_n[KF_COUNT];
+  // pipelined host-buffer path (pn_submit_host_*): created on first use
+  struct Pipe {
+    bool init = false;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t in_ready[2], done[2], delivered[2];
+    void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
+    float *gr[2] = {nullptr, nullptr};
+    int64_t submitted = 0;
+  } pipe;
 };
 
 static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
@@ -199,6 +208,11 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->pipe.init) {
+    hipStreamSynchronize(c->pipe.h2d); hipStreamSynchronize(c->pipe.d2h);
+    for (int k = 0; k < 2; k++) { hipEventDestroy(c->pipe.in_ready[k]); hipEventDestroy(c->pipe.done[k]); hipEventDestroy(c->pipe.delivered[k]); }
+    hipStreamDestroy(c->pipe.h2d); hipStreamDestroy(c->pipe.d2h);
+  }
   for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -308,7 +322,8 @@ fail:
   return NULL;
 }
 
-extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; hipSetDevice(c->device); return zero_state(c); }
+static int pipe_drain(pn_ctx *c);
+extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; hipSetDevice(c->device); if (pipe_drain(c)) return -1; return zero_state(c); }
 extern "C" int pn_ctx_n_streams(const pn_ctx *c) { return c ? c->B : -1; }
 extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
 extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
@@ -467,6 +482,7 @@ extern "C" int pn_process_i16_multi(pn_ctx *c, const int16_t *d_in, int16_t *d_o
 static int process_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
   if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
   PN_HIP_CHECK(hipSetDevice(c->device));
+  if (pipe_drain(c)) return -1;                      // frames still in flight on the pipelined path use io_in/io_out
   const size_t nbytes = (size_t)c->B * PN_FRAME * (is_i16 ? 2 : 4);
   PN_HIP_CHECK(hipMemcpyAsync(c->io_in, h_in, nbytes, hipMemcpyHostToDevice, c->stream));
   if (process_dev(c, c->io_in, c->io_out, NULL, is_i16)) return -1;
@@ -477,6 +493,73 @@ static int process_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, i
 }
 extern "C" int pn_process_host_f32(pn_ctx *c, const float *h_in, float *h_out, float *h_gr) { return process_host(c, h_in, h_out, h_gr, 0); }
 extern "C" int pn_process_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return process_host(c, h_in, h_out, h_gr, 1); }
+
+// ---- pipelined host-buffer path ----------------------------------------------------------------------------
+// Copy-in, the 13 launches and copy-out of consecutive frames on three streams with double-buffered device staging:
+//   h2d stream:     H2D(t) ........ H2D(t+1) ......
+//   compute stream:        frame(t) ........ frame(t+1) ...
+//   d2h stream:                     D2H(t) ......... D2H(t+1)
+// Slot k = t & 1 is reused by frame t+2 only after the host has seen frame t delivered, which also bounds the frames
+// in flight to two.
+static int pipe_init(pn_ctx *c) {
+  pn_ctx::Pipe &P = c->pipe;
+  if (P.init) return 0;
+  PN_HIP_CHECK(hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
+  PN_HIP_CHECK(hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) {
+    PN_HIP_CHECK(hipEventCreateWithFlags(&P.in_ready[k], hipEventDisableTiming));
+    PN_HIP_CHECK(hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
+    PN_HIP_CHECK(hipEventCreateWithFlags(&P.delivered[k], hipEventDisableTiming));
+  }
+  const size_t io_bytes = (size_t)c->B * PN_FRAME * 4, gr_bytes = (size_t)c->B * 68 * 4;
+  P.in[0] = c->io_in; P.out[0] = c->io_out;
+  if (dev_alloc(c, &P.in[1], io_bytes, false) || dev_alloc(c, &P.out[1], io_bytes, false)) return -1;
+  for (int k = 0; k < 2; k++) if (dev_alloc(c, (void **)&P.gr[k], gr_bytes, false)) return -1;
+  P.init = true;
+  return 0;
+}
+
+static int pipe_drain(pn_ctx *c) {
+  if (!c->pipe.init) return 0;
+  PN_HIP_CHECK(hipStreamSynchronize(c->pipe.h2d));
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  PN_HIP_CHECK(hipStreamSynchronize(c->pipe.d2h));
+  return 0;
+}
+
+static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
+  if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  if (pipe_init(c)) return -1;
+  pn_ctx::Pipe &P = c->pipe;
+  const int k = (int)(P.submitted & 1);
+  if (P.submitted >= 2) PN_HIP_CHECK(hipEventSynchronize(P.delivered[k]));     // frame submitted-2 delivered: slot k is free
+  const size_t nbytes = (size_t)c->B * PN_FRAME * (is_i16 ? 2 : 4);
+  PN_HIP_CHECK(hipMemcpyAsync(P.in[k], h_in, nbytes, hipMemcpyHostToDevice, P.h2d));
+  PN_HIP_CHECK(hipEventRecord(P.in_ready[k], P.h2d));
+  PN_HIP_CHECK(hipStreamWaitEvent(c->stream, P.in_ready[k], 0));
+  if (process_dev(c, P.in[k], P.out[k], h_gr ? P.gr[k] : NULL, is_i16)) return -1;
+  PN_HIP_CHECK(hipEventRecord(P.done[k], c->stream));
+  PN_HIP_CHECK(hipStreamWaitEvent(P.d2h, P.done[k], 0));
+  PN_HIP_CHECK(hipMemcpyAsync(h_out, P.out[k], nbytes, hipMemcpyDeviceToHost, P.d2h));
+  if (h_gr) PN_HIP_CHECK(hipMemcpyAsync(h_gr, P.gr[k], (size_t)c->B * 68 * 4, hipMemcpyDeviceToHost, P.d2h));
+  PN_HIP_CHECK(hipEventRecord(P.delivered[k], P.d2h));
+  P.submitted++;
+  return 0;
+}
+extern "C" int pn_submit_host_f32(pn_ctx *c, const float *h_in, float *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 0); }
+extern "C" int pn_submit_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 1); }
+extern "C" int pn_host_wait(pn_ctx *c) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  PN_HIP_CHECK(hipSetDevice(c->device));
+  return pipe_drain(c);
+}
+extern "C" void *pn_host_alloc(size_t bytes) {
+  void *p = NULL;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { pn_set_error("hipHostMalloc(%zu) failed", bytes); return NULL; }
+  return p;
+}
+extern "C" void pn_host_free(void *p) { if (p) hipHostFree(p); }
 
 extern "C" int pn_ctx_read_features(pn_ctx *c, float *h_feat, int32_t *h_silence) {
   if (!c) return -1;

@@ -379,3 +379,33 @@ def test_placement_invariance_across_grid_stride_rounds(model, mode):
             assert (g == g[0]).all(), (t, k, "g/r")
             assert (out[m] == out[m][0]).all(), (t, k, "pcm")
     ctx.close()
+
+
+def test_pipelined_host_path_matches_synchronous(model):
+    """pn_submit_host_i16 / pn_host_wait (copy-in, launches and copy-out of consecutive frames overlapped on three
+    streams, double-buffered staging) == pn_process_host_i16 frame by frame, bit for bit; the families may be mixed."""
+    import torch
+    B, T = 37, 14
+    pcm = synth.synth_batch(B, T + 1, first_stream=2)
+    frames = [np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480]) for t in range(T + 1)]
+    ref_ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    ref = [ref_ctx.process_i16(f) for f in frames]
+    ref_ctx.close()
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    h_in = [torch.from_numpy(f).pin_memory() for f in frames[:T]]
+    h_out = [torch.empty((B, 480), dtype=torch.int16).pin_memory() for _ in range(T)]
+    h_gr = [torch.empty((B, 68), dtype=torch.float32).pin_memory() for _ in range(T)]
+    for t in range(T):
+        ctx.submit_host_i16(h_in[t].data_ptr(), h_out[t].data_ptr(), h_gr[t].data_ptr() if t % 3 else None)
+    ctx.host_wait()
+    for t in range(T):
+        assert np.array_equal(h_out[t].numpy(), ref[t][0]), t
+        if t % 3:
+            assert np.array_equal(h_gr[t].numpy().view(np.uint32), ref[t][1].view(np.uint32)), t
+    o, g = ctx.process_i16(frames[T])                      # synchronous call after pipelined ones: same state
+    assert np.array_equal(o, ref[T][0]) and np.array_equal(g.view(np.uint32), ref[T][1].view(np.uint32))
+    ctx.reset()                                            # and the pipeline restarts cleanly after a reset
+    ctx.submit_host_i16(h_in[0].data_ptr(), h_out[0].data_ptr(), None)
+    ctx.host_wait()
+    assert np.array_equal(h_out[0].numpy(), ref[0][0])
+    ctx.close()
