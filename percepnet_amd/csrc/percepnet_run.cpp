@@ -42,25 +42,43 @@ int main(int argc, char **argv) {
     if (!fin[s] || !fout[s]) { fprintf(stderr, "cannot open %s / %s\n", argv[ai + 2 * s], argv[ai + 2 * s + 1]); return 4; }
   }
   FILE *ftap = (B == 1) ? fopen("feature_test.raw", "wb") : NULL;
-  std::vector<int16_t> in((size_t)B * PN_FRAME_SIZE), out((size_t)B * PN_FRAME_SIZE);
-  std::vector<float> gr((size_t)B * 68);
+  // Three rotating pinned buffer sets on the pipelined entry point: the files of frame t+1 are read while the GPU
+  // works on frame t, and frame t-2's output is on the host once pn_submit_host_i16(t) has returned.
+  struct Slot { int16_t *in, *out; float *gr; std::vector<char> alive; };
+  Slot slot[3];
+  for (Slot &sl : slot) {
+    sl.in = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
+    sl.out = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
+    sl.gr = (float *)pn_host_alloc((size_t)B * 68 * sizeof(float));
+    if (!sl.in || !sl.out || !sl.gr) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+    sl.alive.assign(B, 0);
+  }
   std::vector<char> alive(B, 1), first(B, 1);
-  int n_alive = B;
-  while (n_alive > 0) {
+  auto flush = [&](const Slot &sl) {                 // main.cpp:36-38 for every stream that supplied this frame
     for (int s = 0; s < B; s++) {
-      int16_t *x = &in[(size_t)s * PN_FRAME_SIZE];
+      if (!sl.alive[s]) continue;
+      if (ftap) fwrite(&sl.gr[(size_t)s * 68], sizeof(float), 68, ftap);
+      if (!first[s]) fwrite(&sl.out[(size_t)s * PN_FRAME_SIZE], sizeof(int16_t), PN_FRAME_SIZE, fout[s]);
+      first[s] = 0;
+    }
+  };
+  int n_alive = B;
+  long t = 0;
+  for (;; t++) {
+    Slot &sl = slot[t % 3];
+    for (int s = 0; s < B; s++) {
+      int16_t *x = sl.in + (size_t)s * PN_FRAME_SIZE;
       if (alive[s] && fread(x, sizeof(int16_t), PN_FRAME_SIZE, fin[s]) != PN_FRAME_SIZE) { alive[s] = 0; n_alive--; }
       if (!alive[s]) memset(x, 0, PN_FRAME_SIZE * sizeof(int16_t));
     }
     if (n_alive == 0) break;
-    if (pn_process_host_i16(cx, in.data(), out.data(), gr.data())) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
-    for (int s = 0; s < B; s++) {
-      if (!alive[s]) continue;
-      if (ftap) fwrite(&gr[(size_t)s * 68], sizeof(float), 68, ftap);
-      if (!first[s]) fwrite(&out[(size_t)s * PN_FRAME_SIZE], sizeof(int16_t), PN_FRAME_SIZE, fout[s]);
-      first[s] = 0;
-    }
+    sl.alive = alive;
+    if (pn_submit_host_i16(cx, sl.in, sl.out, sl.gr)) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+    if (t >= 2) flush(slot[(t - 2) % 3]);
   }
+  if (pn_host_wait(cx)) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+  for (long u = (t >= 2 ? t - 2 : 0); u < t; u++) flush(slot[u % 3]);     // the last two frames in flight
+  for (Slot &sl : slot) { pn_host_free(sl.in); pn_host_free(sl.out); pn_host_free(sl.gr); }
   for (int s = 0; s < B; s++) { fclose(fin[s]); fclose(fout[s]); }
   if (ftap) fclose(ftap);
   pn_ctx_destroy(cx); pn_model_free(m);
