@@ -114,7 +114,11 @@ int pn_ctx_synchronize(pn_ctx *ctx);
 /* Mid-pipeline taps for per-stage parity tests (device -> host copies, synchronising).
    features: [n_streams][70] of the last frame; silence: [n_streams] int32. */
 int pn_ctx_read_features(pn_ctx *ctx, float *h_feat, int32_t *h_silence);
-/* Run only the network on host-supplied features [n_streams][70] -> g,r [n_streams][68]. */
+/* The same tap into caller-owned DEVICE buffers, asynchronous on the context's stream (either may be NULL). */
+int pn_ctx_read_features_dev(pn_ctx *ctx, float *d_feat, int32_t *d_silence);
+/* Run only the network on host-supplied features [n_streams][70] -> g,r [n_streams][68]: compute_rnn (rnn.cpp:42-81)
+   on the context's RNN state.  Advances only the network's state (conv FIFOs, GRUs), like calling the reference's
+   compute_rnn on an RNNState directly; the DSP state and frame counter of pn_process_* are untouched. */
 int pn_ctx_compute_rnn_host(pn_ctx *ctx, const float *h_feat, float *h_gr);
 
 /* ---- per-kernel timing (HIP events on the context's stream) ------------------------------- */

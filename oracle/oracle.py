@@ -48,6 +48,8 @@ class Oracle:
         L.pno_run_pcm.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, c_s, c_f]
         L.pno_run_pcm_pf.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, c_s, c_f, ctypes.c_int]
         L.pno_run_float.argtypes = [ctypes.c_void_p, c_f, ctypes.c_int, c_f, c_f]
+        L.pno_run_pcm_batch.argtypes = [ctypes.c_void_p, c_s, ctypes.c_int, ctypes.c_int, c_s, c_f, c_f, c_i,
+                                        ctypes.c_int, ctypes.c_int]
         L.pno_frame_features.argtypes = [ctypes.c_void_p, c_f, c_f]
         L.pno_frame_features.restype = ctypes.c_int
         L.pno_compute_rnn.argtypes = [ctypes.c_void_p, c_f, c_f, c_f]
@@ -79,6 +81,27 @@ class Oracle:
         gr = np.zeros((n, 68), np.float32)
         self.lib.pno_run_float(self.model, _fp(x), n, _fp(out), _fp(gr))
         return out, gr
+
+    def run_batch(self, pcm, want_feat=True, group=16, threads=None):
+        """run_pcm for many streams on all host cores (pno_run_pcm_batch: the same per-stream arithmetic, groups of
+        streams sharing each sweep over the weights).  pcm int16 [S, T*480] ->
+        (out int16 [S, (T-1)*480], gr [S, T, 68], feat [S, T, 70] | None, silence int32 [S, T] | None)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        S = pcm.shape[0]; T = pcm.shape[1] // 480
+        assert pcm.shape[1] == T * 480
+        if threads is None:
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+        out = np.zeros((S, max(T - 1, 0) * 480), np.int16)
+        gr = np.zeros((S, T, 68), np.float32)
+        feat = np.zeros((S, T, 70), np.float32) if want_feat else None
+        sil = np.zeros((S, T), np.int32) if want_feat else None
+        self.lib.pno_run_pcm_batch(self.model, pcm.ctypes.data_as(c_s), S, T, out.ctypes.data_as(c_s), _fp(gr),
+                                   _fp(feat) if want_feat else None, sil.ctypes.data_as(c_i) if want_feat else None,
+                                   int(group), int(threads))
+        return out, gr, feat, sil
 
     def features(self, x):
         """Per-frame 70 features + silence flag, DSP only (no NN)."""

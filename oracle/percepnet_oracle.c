@@ -629,28 +629,26 @@ static void post_filtering(float *g, const float *Ey);
    after compute_rnn and the g/r tap (531-534), before pitch_filter (536); the tap keeps the network's raw g. */
 void pno_set_postfilter(pno_state *st, int on) { st->postfilter = on != 0; }
 
-void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68) {
-  frame_ana a; float features[70], g[NB], r[NB], gf[FREQ], rf[FREQ], inv_r[NB];
+/* everything of rnnoise_process_frame after compute_rnn (denoise.cpp:531-546): the tap, pitch_filter, the gain,
+   inverse transform and overlap-add.  Shared by the single-stream and the batched drivers. */
+static void frame_finish(pno_state *st, frame_ana *a, float *g, const float *r, float *out) {
+  float gf[FREQ], rf[FREQ], inv_r[NB];
   cpx x[WINDOW], y[WINDOW]; float t[WINDOW]; int i;
-  frame_features(st, &a, in);
-  make_features(st, &a, features);
-  pno_compute_rnn(st, g, r, features);
-  if (gr68) { memcpy(gr68, g, sizeof(g)); memcpy(gr68 + NB, r, sizeof(r)); }
-  if (st->postfilter) post_filtering(g, a.Ex);
-  if (!a.silence) {                                          /* pitch_filter 436-485 */
+  if (st->postfilter) post_filtering(g, a->Ex);
+  if (!a->silence) {                                         /* pitch_filter 436-485 */
     for (i = 0; i < FREQ; i++) rf[i] = 0;
     for (i = 0; i < NB; i++) inv_r[i] = 1 - r[i];
     interp_band_gain(rf, inv_r);
-    for (i = 0; i < FREQ; i++) { a.X[i].r = rf[i] * a.X[i].r; a.X[i].i = rf[i] * a.X[i].i; }
+    for (i = 0; i < FREQ; i++) { a->X[i].r = rf[i] * a->X[i].r; a->X[i].i = rf[i] * a->X[i].i; }
     interp_band_gain(rf, r);
-    for (i = 0; i < FREQ; i++) { a.X[i].r += rf[i] * a.P[i].r; a.X[i].i += rf[i] * a.P[i].i; }
+    for (i = 0; i < FREQ; i++) { a->X[i].r += rf[i] * a->P[i].r; a->X[i].i += rf[i] * a->P[i].i; }
   }
   for (i = 0; i < FREQ; i++) gf[i] = 0;                      /* gf[]={1} then bins<400 rewritten 517,539 */
   interp_band_gain(gf, g);
-  for (i = 0; i < FREQ; i++) { a.X[i].r *= gf[i]; a.X[i].i *= gf[i]; }
+  for (i = 0; i < FREQ; i++) { a->X[i].r *= gf[i]; a->X[i].i *= gf[i]; }
   /* frame_synthesis 352-359 / inverse_transform 306-324: Hermitian extension, FORWARD fft,
      reversed read-out, x960 */
-  for (i = 0; i < FREQ; i++) x[i] = a.X[i];
+  for (i = 0; i < FREQ; i++) x[i] = a->X[i];
   for (; i < WINDOW; i++) { x[i].r = x[WINDOW - i].r; x[i].i = -x[WINDOW - i].i; }
   fft960(x, y);
   t[0] = WINDOW * y[0].r;
@@ -658,6 +656,15 @@ void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68) 
   for (i = 0; i < FRAME; i++) { t[i] *= g_half_window[i]; t[WINDOW - 1 - i] *= g_half_window[i]; }
   for (i = 0; i < FRAME; i++) out[i] = t[i] + st->synthesis_mem[i];
   memcpy(st->synthesis_mem, t + FRAME, FRAME * sizeof(float));
+}
+
+void pno_process_frame(pno_state *st, float *out, const float *in, float *gr68) {
+  frame_ana a; float features[70], g[NB], r[NB];
+  frame_features(st, &a, in);
+  make_features(st, &a, features);
+  pno_compute_rnn(st, g, r, features);
+  if (gr68) { memcpy(gr68, g, sizeof(g)); memcpy(gr68 + NB, r, sizeof(r)); }
+  frame_finish(st, &a, g, r, out);
 }
 
 /* float -> short as the CLI's x86-64 build does it (main.cpp:36: cvttss2si then the low 16
@@ -688,6 +695,209 @@ void pno_run_float(const pno_model *m, const float *in, int n_frames, float *out
   pno_destroy(st);
 }
 
+
+/* ================================================================== batched driver (test speed only)
+ * pno_run_pcm for many streams at once.  The per-stream arithmetic is IDENTICAL to the single-stream
+ * functions above — every output of every stream is produced by the same sequence of separately
+ * rounded IEEE binary32 operations (bias, then j-ascending `acc = acc + w*x`, nnet.cpp:59-72) — only
+ * the loop nest differs: a group of streams shares one sweep over the 32 MB of weights (the
+ * single-stream loop is bound by re-streaming them every frame) and groups are spread over host
+ * threads.  tests/test_oracle.py::test_batched_oracle_is_bit_identical pins this driver to
+ * pno_run_pcm / pno_frame_features bit for bit; it exists so that the GPU parity tests can afford
+ * BASELINE's sizes (1024 streams x 1000 frames). */
+#include <pthread.h>
+
+#define BG_MAX 32            /* streams per group (share a weight sweep) */
+typedef float v8f __attribute__((vector_size(32), aligned(4), may_alias));
+
+/* out[g][i] += sum_j w[j*stride+i]*x[g][j], j ascending, mul then add, for 4 streams x 16 outputs */
+__attribute__((target_clones("avx2", "default")))
+static void sgemv_accum_4x16(float *out, int ldo, const float *w, int cols, int stride, const float *x, int ldx) {
+  v8f a00 = *(v8f *)(out), a01 = *(v8f *)(out + 8);
+  v8f a10 = *(v8f *)(out + ldo), a11 = *(v8f *)(out + ldo + 8);
+  v8f a20 = *(v8f *)(out + 2 * ldo), a21 = *(v8f *)(out + 2 * ldo + 8);
+  v8f a30 = *(v8f *)(out + 3 * ldo), a31 = *(v8f *)(out + 3 * ldo + 8);
+  int j;
+  for (j = 0; j < cols; j++) {
+    const v8f w0 = *(const v8f *)(w + (size_t)j * stride), w1 = *(const v8f *)(w + (size_t)j * stride + 8);
+    const float x0 = x[j], x1 = x[ldx + j], x2 = x[2 * ldx + j], x3 = x[3 * ldx + j];
+    a00 = a00 + w0 * x0; a01 = a01 + w1 * x0;
+    a10 = a10 + w0 * x1; a11 = a11 + w1 * x1;
+    a20 = a20 + w0 * x2; a21 = a21 + w1 * x2;
+    a30 = a30 + w0 * x3; a31 = a31 + w1 * x3;
+  }
+  *(v8f *)(out) = a00; *(v8f *)(out + 8) = a01;
+  *(v8f *)(out + ldo) = a10; *(v8f *)(out + ldo + 8) = a11;
+  *(v8f *)(out + 2 * ldo) = a20; *(v8f *)(out + 2 * ldo + 8) = a21;
+  *(v8f *)(out + 3 * ldo) = a30; *(v8f *)(out + 3 * ldo + 8) = a31;
+}
+
+static void sgemv_accum_b(float *out, int ldo, const float *w, int rows, int cols, int stride, const float *x, int ldx, int G) {
+  int i0, g0, g, i, j;
+  for (i0 = 0; i0 < rows; i0 += 16) {
+    const int nb = rows - i0 < 16 ? rows - i0 : 16;
+    for (g0 = 0; g0 < G; g0 += 4) {
+      const int gb = G - g0 < 4 ? G - g0 : 4;
+      if (nb == 16 && gb == 4) { sgemv_accum_4x16(out + (size_t)g0 * ldo + i0, ldo, w + i0, cols, stride, x + (size_t)g0 * ldx, ldx); continue; }
+      for (g = g0; g < g0 + gb; g++)
+        for (i = i0; i < i0 + nb; i++) {
+          float acc = out[(size_t)g * ldo + i];
+          for (j = 0; j < cols; j++) acc = acc + w[(size_t)j * stride + i] * x[(size_t)g * ldx + j];
+          out[(size_t)g * ldo + i] = acc;
+        }
+    }
+  }
+}
+
+static void dense_b(const layer_t *L, float *out, int ldo, const float *in, int ldi, int G) {
+  int g, i;
+  for (g = 0; g < G; g++) for (i = 0; i < L->nn; i++) out[(size_t)g * ldo + i] = L->bias[i];
+  sgemv_accum_b(out, ldo, L->w, L->nn, L->nin, L->nn, in, ldi, G);
+  for (g = 0; g < G; g++) activation(out + (size_t)g * ldo, L->nn, L->act);
+}
+/* compute_conv1d nnet.cpp:182-200; mem[g] points at stream g's FIFO */
+static void conv1d_b(const layer_t *L, float *out, float *const *mem, const float *in, float *tmp /*[G][1536]*/, int G) {
+  const int nin = L->nin, ks = L->ks, nn = L->nn; int g, i;
+  for (g = 0; g < G; g++) {
+    memcpy(tmp + (size_t)g * 1536, mem[g], sizeof(float) * nin * (ks - 1));
+    memcpy(tmp + (size_t)g * 1536 + nin * (ks - 1), in + (size_t)g * nin, sizeof(float) * nin);
+    for (i = 0; i < nn; i++) out[(size_t)g * nn + i] = L->bias[i];
+  }
+  sgemv_accum_b(out, nn, L->w, nn, nin * ks, nn, tmp, 1536, G);
+  for (g = 0; g < G; g++) {
+    activation(out + (size_t)g * nn, nn, L->act);
+    memcpy(mem[g], tmp + (size_t)g * 1536 + nin, sizeof(float) * nin * (ks - 1));
+  }
+}
+/* compute_gru nnet.cpp:120-180 (reset_after), statement for statement as pno_gru; state[g] = stream g's state */
+static void gru_b(const layer_t *L, float *const *state, const float *in, int ldi, float *ws /*[5][G][512]*/, int G) {
+  const int M = L->nin, N = L->nn, stride = 3 * N; const float *b = L->bias; int g, i;
+  float *z = ws, *r = ws + (size_t)G * 512, *h = ws + (size_t)2 * G * 512, *tmp = ws + (size_t)3 * G * 512, *sc = ws + (size_t)4 * G * 512;
+  for (g = 0; g < G; g++) {
+    float *zg = z + (size_t)g * 512, *rg = r + (size_t)g * 512, *hg = h + (size_t)g * 512, *tg = tmp + (size_t)g * 512;
+    memcpy(sc + (size_t)g * 512, state[g], sizeof(float) * N);
+    for (i = 0; i < N; i++) zg[i] = b[i];
+    for (i = 0; i < N; i++) zg[i] += b[3 * N + i];
+    for (i = 0; i < N; i++) rg[i] = b[N + i];
+    for (i = 0; i < N; i++) rg[i] += b[4 * N + i];
+    for (i = 0; i < N; i++) hg[i] = b[2 * N + i];
+    for (i = 0; i < N; i++) tg[i] = b[5 * N + i];
+  }
+  sgemv_accum_b(z, 512, L->w, N, M, stride, in, ldi, G);
+  sgemv_accum_b(z, 512, L->rw, N, N, stride, sc, 512, G);
+  sgemv_accum_b(r, 512, L->w + N, N, M, stride, in, ldi, G);
+  sgemv_accum_b(r, 512, L->rw + N, N, N, stride, sc, 512, G);
+  sgemv_accum_b(tmp, 512, L->rw + 2 * N, N, N, stride, sc, 512, G);
+  for (g = 0; g < G; g++) {
+    float *zg = z + (size_t)g * 512, *rg = r + (size_t)g * 512, *hg = h + (size_t)g * 512, *tg = tmp + (size_t)g * 512;
+    activation(zg, N, ACT_SIGMOID);
+    activation(rg, N, ACT_SIGMOID);
+    for (i = 0; i < N; i++) hg[i] += tg[i] * rg[i];
+  }
+  sgemv_accum_b(h, 512, L->w + 2 * N, N, M, stride, in, ldi, G);
+  for (g = 0; g < G; g++) {
+    float *zg = z + (size_t)g * 512, *hg = h + (size_t)g * 512, *st = state[g];
+    activation(hg, N, L->act);
+    for (i = 0; i < N; i++) hg[i] = zg[i] * st[i] + (1 - zg[i]) * hg[i];
+    for (i = 0; i < N; i++) st[i] = hg[i];
+  }
+}
+
+typedef struct {
+  float feat[BG_MAX][70], fc[BG_MAX][128], c1[BG_MAX][512], c2[BG_MAX][512], ctmp[BG_MAX][1536];
+  float gru_in[BG_MAX][512], rb_in[BG_MAX][1024], gb_in[BG_MAX][2560], gws[5][BG_MAX][512], g[BG_MAX][NB], r[BG_MAX][NB];
+  frame_ana ana[BG_MAX];
+} batch_ws;
+
+/* compute_rnn rnn.cpp:42-81 for G streams */
+static void compute_rnn_b(pno_state *const *st, batch_ws *W, int G) {
+  const layer_t *L = st[0]->m->L; float *ptr[BG_MAX]; int g;
+  dense_b(&L[L_FC], &W->fc[0][0], 128, &W->feat[0][0], 70, G);
+  for (g = 0; g < G; g++) ptr[g] = st[g]->conv1_mem;
+  conv1d_b(&L[L_CONV1], &W->c1[0][0], ptr, &W->fc[0][0], &W->ctmp[0][0], G);
+  for (g = 0; g < G; g++) ptr[g] = st[g]->conv2_mem;
+  conv1d_b(&L[L_CONV2], &W->c2[0][0], ptr, &W->c1[0][0], &W->ctmp[0][0], G);
+  for (g = 0; g < G; g++) ptr[g] = st[g]->gru1;
+  gru_b(&L[L_GRU1], ptr, &W->c2[0][0], 512, &W->gws[0][0][0], G);
+  for (g = 0; g < G; g++) { memcpy(W->gru_in[g], st[g]->gru1, 2048); ptr[g] = st[g]->gru2; }
+  gru_b(&L[L_GRU2], ptr, &W->gru_in[0][0], 512, &W->gws[0][0][0], G);
+  for (g = 0; g < G; g++) { memcpy(W->gru_in[g], st[g]->gru2, 2048); ptr[g] = st[g]->gru3; }
+  gru_b(&L[L_GRU3], ptr, &W->gru_in[0][0], 512, &W->gws[0][0][0], G);
+  for (g = 0; g < G; g++) { memcpy(W->gru_in[g], st[g]->gru3, 2048); ptr[g] = st[g]->gru_gb; }
+  gru_b(&L[L_GRU_GB], ptr, &W->gru_in[0][0], 512, &W->gws[0][0][0], G);
+  for (g = 0; g < G; g++) {
+    memcpy(W->rb_in[g], st[g]->gru3, 2048); memcpy(W->rb_in[g] + 512, W->c2[g], 2048);
+    ptr[g] = st[g]->gru_rb;
+  }
+  gru_b(&L[L_GRU_RB], ptr, &W->rb_in[0][0], 1024, &W->gws[0][0][0], G);
+  for (g = 0; g < G; g++) {
+    memcpy(W->gb_in[g], W->c2[g], 2048); memcpy(W->gb_in[g] + 512, st[g]->gru1, 2048); memcpy(W->gb_in[g] + 1024, st[g]->gru2, 2048);
+    memcpy(W->gb_in[g] + 1536, st[g]->gru3, 2048); memcpy(W->gb_in[g] + 2048, st[g]->gru_gb, 2048);
+    memcpy(W->gru_in[g], st[g]->gru_rb, 512);
+  }
+  dense_b(&L[L_FC_GB], &W->g[0][0], NB, &W->gb_in[0][0], 2560, G);
+  dense_b(&L[L_FC_RB], &W->r[0][0], NB, &W->gru_in[0][0], 512, G);
+}
+
+typedef struct {
+  const pno_model *m; const short *pcm_in; int S, T, G; short *pcm_out; float *gr, *feat; int *sil;
+  int next_group;
+} batch_job;
+
+static void *batch_worker(void *arg) {
+  batch_job *J = (batch_job *)arg;
+  const int n_groups = (J->S + J->G - 1) / J->G, T = J->T;
+  batch_ws *W = (batch_ws *)malloc(sizeof(batch_ws));
+  pno_state *st[BG_MAX]; float x[FRAME]; int g, t, i;
+  for (;;) {
+    const int grp = __atomic_fetch_add(&J->next_group, 1, __ATOMIC_RELAXED);
+    int s0, G;
+    if (grp >= n_groups) break;
+    s0 = grp * J->G; G = J->S - s0 < J->G ? J->S - s0 : J->G;
+    for (g = 0; g < G; g++) st[g] = pno_create(J->m);
+    for (t = 0; t < T; t++) {
+      for (g = 0; g < G; g++) {
+        const size_t s = (size_t)(s0 + g);
+        const short *in = J->pcm_in + (s * T + t) * FRAME;
+        for (i = 0; i < FRAME; i++) x[i] = ((float)in[i]) / 32768.f;          /* main.cpp:34 */
+        frame_features(st[g], &W->ana[g], x);
+        make_features(st[g], &W->ana[g], W->feat[g]);
+        if (J->feat) memcpy(J->feat + (s * T + t) * 70, W->feat[g], 70 * sizeof(float));
+        if (J->sil) J->sil[s * T + t] = W->ana[g].silence;
+      }
+      compute_rnn_b(st, W, G);
+      for (g = 0; g < G; g++) {
+        const size_t s = (size_t)(s0 + g);
+        if (J->gr) { memcpy(J->gr + (s * T + t) * 68, W->g[g], NB * 4); memcpy(J->gr + (s * T + t) * 68 + NB, W->r[g], NB * 4); }
+        frame_finish(st[g], &W->ana[g], W->g[g], W->r[g], x);
+        if (t > 0 && J->pcm_out) {                                             /* main.cpp:36-38 */
+          short *o = J->pcm_out + (s * (size_t)(T - 1) + (size_t)(t - 1)) * FRAME;
+          for (i = 0; i < FRAME; i++) o[i] = f2s(x[i] * 32768);
+        }
+      }
+    }
+    for (g = 0; g < G; g++) pno_destroy(st[g]);
+  }
+  free(W);
+  return NULL;
+}
+
+/* pcm_in [S][T*480]; pcm_out [S][(T-1)*480]; gr [S][T][68]; feat [S][T][70]; sil [S][T] (any output may be NULL) */
+void pno_run_pcm_batch(const pno_model *m, const short *pcm_in, int n_streams, int n_frames, short *pcm_out,
+                       float *gr, float *feat, int *sil, int group, int n_threads) {
+  batch_job J; pthread_t th[512]; int i, n_groups;
+  init_tables(); pno_tansig_table();        /* lazy tables built before the threads start */
+  if (group < 1) group = 16;
+  if (group > BG_MAX) group = BG_MAX;
+  J.m = m; J.pcm_in = pcm_in; J.S = n_streams; J.T = n_frames; J.G = group; J.pcm_out = pcm_out; J.gr = gr; J.feat = feat; J.sil = sil;
+  J.next_group = 0;
+  n_groups = (n_streams + group - 1) / group;
+  if (n_threads > n_groups) n_threads = n_groups;
+  if (n_threads > 512) n_threads = 512;
+  if (n_threads <= 1) { batch_worker(&J); return; }
+  for (i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, batch_worker, &J);
+  for (i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+}
 
 /* ================================================================== training-feature generator
  * one iteration of the `percepNet` binary's train() loop, denoise.cpp:655-778,

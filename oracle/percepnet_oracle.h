@@ -38,6 +38,11 @@ void pno_run_pcm(const pno_model *m, const short *pcm_in, int n_frames, short *p
 void pno_set_postfilter(pno_state *st, int on);
 void pno_run_pcm_pf(const pno_model *m, const short *pcm_in, int n_frames, short *pcm_out, float *gr, int postfilter);
 void pno_run_float(const pno_model *m, const float *in, int n_frames, float *out, float *gr);
+/* pno_run_pcm for n_streams streams on n_threads host threads, `group` streams sharing each sweep over the
+   weights (same per-stream arithmetic, bit-identical results; pinned by tests/test_oracle.py).
+   pcm_in [S][T*480]; pcm_out [S][(T-1)*480]; gr [S][T][68]; feat [S][T][70]; sil [S][T]; outputs may be NULL */
+void pno_run_pcm_batch(const pno_model *m, const short *pcm_in, int n_streams, int n_frames, short *pcm_out,
+                       float *gr, float *feat, int *sil, int group, int n_threads);
 
 /* ---- stage functions (exported for per-stage parity tests) ---- */
 void pno_fft960(const float *in_ri, float *out_ri);

@@ -66,6 +66,7 @@ def load_library():
     L.pn_ctx_synchronize.argtypes = [_vp]
     L.pn_ctx_set_postfilter.argtypes = [_vp, ctypes.c_int]
     L.pn_ctx_read_features.argtypes = [_vp, _vp, _vp]
+    L.pn_ctx_read_features_dev.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_compute_rnn_host.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_set_profiling.argtypes = [_vp, ctypes.c_int]
     L.pn_kernel_name.restype = ctypes.c_char_p
@@ -200,6 +201,10 @@ class Context:
         sil = np.empty(self.n_streams, np.int32)
         self._chk(self.L.pn_ctx_read_features(self.h, feat.ctypes.data, sil.ctypes.data))
         return feat, sil
+
+    def read_features_dev(self, d_feat, d_sil=None):
+        """Device-pointer twin of read_features (async on the context's stream)."""
+        self._chk(self.L.pn_ctx_read_features_dev(self.h, d_feat, d_sil))
 
     def compute_rnn(self, feat):
         feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(self.n_streams, 70)

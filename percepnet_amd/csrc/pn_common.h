@@ -60,3 +60,16 @@ struct pn_model {
   } while (0)
 
 void pn_set_error(const char *fmt, ...);
+
+// Every entry point runs on the context's device and leaves the caller's current device as it found it (callers
+// hand in torch data_ptr()s from a thread whose current device torch manages).
+struct DeviceGuard {
+  int prev = -1; bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    if (prev == dev) prev = -1;                       // nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+#define PN_ON_DEVICE(c) DeviceGuard _dg((c)->device); if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", (c)->device); return -1; }

@@ -127,7 +127,10 @@ struct pn_ctx {
   int device, B, nn_mode;
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
-  int64_t t;                       // frames done
+  int64_t t;                       // frames done: indexes the DSP rings (hist slot t%12, yring/eyring t%6)
+  int64_t tn;                      // network steps done: indexes the conv rings (tn%5, tn%3) and the GRU ping-pong (tn&1).
+                                   // == t unless pn_ctx_compute_rnn_host advanced the network on its own (rnn.cpp:42 is
+                                   // callable on an RNNState without a DenoiseState in the reference too)
   size_t bytes;
   PnLayerHost geom[PN_NLAYERS];
   DevLayer L[PN_NLAYERS];
@@ -200,13 +203,13 @@ static int zero_state(pn_ctx *c) {
     for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gruH[i], 0, 2 * Bp * 512 * 2, c->stream));
     PN_HIP_CHECK(hipMemsetAsync(c->rbH, 0, 2 * Bp * 128 * 2, c->stream));
   }
-  c->t = 0;
+  c->t = 0; c->tn = 0;
   return 0;
 }
 
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
-  hipSetDevice(c->device);
+  DeviceGuard _dg(c->device);
   hipStreamSynchronize(c->stream);
   if (c->pipe.init) {
     hipStreamSynchronize(c->pipe.h2d); hipStreamSynchronize(c->pipe.d2h);
@@ -229,9 +232,10 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
     return NULL;
   }
   if (device < 0 || device >= ndev) { pn_set_error("device %d out of range (%d devices)", device, ndev); return NULL; }
-  if (hipSetDevice(device) != hipSuccess) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
+  DeviceGuard _dg(device);
+  if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -323,11 +327,11 @@ fail:
 }
 
 static int pipe_drain(pn_ctx *c);
-extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; hipSetDevice(c->device); if (pipe_drain(c)) return -1; return zero_state(c); }
+extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); if (pipe_drain(c)) return -1; return zero_state(c); }
 extern "C" int pn_ctx_n_streams(const pn_ctx *c) { return c ? c->B : -1; }
 extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
 extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
-extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
 
 // ---- profiling ------------------------------------------------------------------------------------------
 struct Scope {
@@ -393,7 +397,7 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
 }
 
 static void launch_rnn(pn_ctx *c) {
-  const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->t;
+  const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
   const bool f16 = c->nn_mode == PN_NN_MFMA_F16;
   hipStream_t st = c->stream; const float *tab = c->tansig;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
@@ -446,7 +450,7 @@ static void launch_rnn(pn_ctx *c) {
 
 static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16) {
   if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
   { Scope sc(c, KF_FRONTEND);
     pn_launch_frontend(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring,
                        c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr); }
@@ -459,7 +463,8 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
     pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, Ex, c->silence, c->synth, d_out, is_i16); }
   if (d_gr) PN_HIP_CHECK(hipMemcpyAsync(d_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToDevice, c->stream));
   PN_HIP_CHECK(hipGetLastError());
-  c->t++;
+  c->t++; c->tn++;
+  if (c->events.size() >= 4096 && flush_events(c)) return -1;   // profiling left on: bound the pending events
   return 0;
 }
 
@@ -481,7 +486,7 @@ extern "C" int pn_process_i16_multi(pn_ctx *c, const int16_t *d_in, int16_t *d_o
 
 static int process_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
   if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
   if (pipe_drain(c)) return -1;                      // frames still in flight on the pipelined path use io_in/io_out
   const size_t nbytes = (size_t)c->B * PN_FRAME * (is_i16 ? 2 : 4);
   PN_HIP_CHECK(hipMemcpyAsync(c->io_in, h_in, nbytes, hipMemcpyHostToDevice, c->stream));
@@ -529,7 +534,7 @@ static int pipe_drain(pn_ctx *c) {
 
 static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
   if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
   if (pipe_init(c)) return -1;
   pn_ctx::Pipe &P = c->pipe;
   const int k = (int)(P.submitted & 1);
@@ -551,7 +556,7 @@ extern "C" int pn_submit_host_f32(pn_ctx *c, const float *h_in, float *h_out, fl
 extern "C" int pn_submit_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 1); }
 extern "C" int pn_host_wait(pn_ctx *c) {
   if (!c) { pn_set_error("NULL argument"); return -1; }
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
   return pipe_drain(c);
 }
 extern "C" void *pn_host_alloc(size_t bytes) {
@@ -563,7 +568,7 @@ extern "C" void pn_host_free(void *p) { if (p) hipHostFree(p); }
 
 extern "C" int pn_ctx_read_features(pn_ctx *c, float *h_feat, int32_t *h_silence) {
   if (!c) return -1;
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
   if (h_feat)
     PN_HIP_CHECK(hipMemcpy2DAsync(h_feat, PN_NFEAT * 4, c->feat, PN_FEAT_STRIDE * 4, PN_NFEAT * 4, c->B, hipMemcpyDeviceToHost, c->stream));
   if (h_silence) PN_HIP_CHECK(hipMemcpyAsync(h_silence, c->silence, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
@@ -571,15 +576,27 @@ extern "C" int pn_ctx_read_features(pn_ctx *c, float *h_feat, int32_t *h_silence
   return 0;
 }
 
+// Device-side twin of pn_ctx_read_features: asynchronous copies on the context's stream into caller-owned device
+// buffers (d_feat [n_streams][70], d_silence [n_streams] int32; either may be NULL).
+extern "C" int pn_ctx_read_features_dev(pn_ctx *c, float *d_feat, int32_t *d_silence) {
+  if (!c) return -1;
+  PN_ON_DEVICE(c);
+  if (d_feat)
+    PN_HIP_CHECK(hipMemcpy2DAsync(d_feat, PN_NFEAT * 4, c->feat, PN_FEAT_STRIDE * 4, PN_NFEAT * 4, c->B, hipMemcpyDeviceToDevice, c->stream));
+  if (d_silence) PN_HIP_CHECK(hipMemcpyAsync(d_silence, c->silence, (size_t)c->B * 4, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
 extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_gr) {
   if (!c || !h_feat || !h_gr) { pn_set_error("NULL argument"); return -1; }
-  PN_HIP_CHECK(hipSetDevice(c->device));
+  PN_ON_DEVICE(c);
+  if (pipe_drain(c)) return -1;                      // frames in flight on the pipelined path own feat/gr
   PN_HIP_CHECK(hipMemcpy2DAsync(c->feat, PN_FEAT_STRIDE * 4, h_feat, PN_NFEAT * 4, PN_NFEAT * 4, c->B, hipMemcpyHostToDevice, c->stream));
   launch_rnn(c);
   PN_HIP_CHECK(hipMemcpyAsync(h_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToHost, c->stream));
   PN_HIP_CHECK(hipStreamSynchronize(c->stream));
   PN_HIP_CHECK(hipGetLastError());
-  c->t++;
+  c->tn++;                                           // only the network's rings advance; the DSP rings keep their frame
   return 0;
 }
 
@@ -604,7 +621,7 @@ extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long lon
     default: pn_set_error("bad debug buffer id"); return -1;
   }
   if ((long long)n > max_bytes) { pn_set_error("debug buffer needs %zu bytes", n); return -1; }
-  if (hipSetDevice(c->device) != hipSuccess) return -1;
+  PN_ON_DEVICE(c);
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
   if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) { pn_set_error("debug copy failed"); return -1; }
   return (long long)n;

@@ -47,7 +47,7 @@ static int fg_zero_side(pn_featgen *c, FgSide &s) {
 
 extern "C" void pn_featgen_destroy(pn_featgen *c) {
   if (!c) return;
-  hipSetDevice(c->device);
+  DeviceGuard _dg(c->device);
   hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -62,7 +62,8 @@ extern "C" pn_featgen *pn_featgen_create(int device, int n_pairs, void *hip_stre
     return NULL;
   }
   if (device < 0 || device >= ndev) { pn_set_error("device %d out of range (%d devices)", device, ndev); return NULL; }
-  if (hipSetDevice(device) != hipSuccess) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
+  DeviceGuard _dg(device);
+  if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_featgen *c = new pn_featgen();
   c->device = device; c->B = n_pairs; c->t = 0; c->bytes = 0;
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -104,7 +105,7 @@ fail:
 
 extern "C" int pn_featgen_reset(pn_featgen *c) {
   if (!c) return -1;
-  hipSetDevice(c->device);
+  PN_ON_DEVICE(c);
   if (fg_zero_side(c, c->clean) || fg_zero_side(c, c->noisy)) return -1;
   PN_HIP_CHECK(hipMemsetAsync(c->synth, 0, (size_t)c->B * PN_FRAME * 4, c->stream));
   c->t = 0;
@@ -142,14 +143,14 @@ static int fg_frame(pn_featgen *c, const int16_t *sp, const int16_t *no, long lo
 extern "C" int pn_featgen_process_i16(pn_featgen *c, const int16_t *d_speech, const int16_t *d_noisy, float *d_records,
                                       int16_t *d_test_pcm) {
   if (!c || !d_speech || !d_noisy || !d_records) { pn_set_error("NULL argument"); return -1; }
-  hipSetDevice(c->device);
+  PN_ON_DEVICE(c);
   return fg_frame(c, d_speech, d_noisy, PN_FRAME, d_records, 138, d_test_pcm, PN_FRAME);
 }
 
 extern "C" int pn_featgen_process_i16_files(pn_featgen *c, const int16_t *d_speech, const int16_t *d_noisy,
                                             int n_frames, float *d_records, int16_t *d_test_pcm) {
   if (!c || !d_speech || !d_noisy || !d_records || n_frames < 0) { pn_set_error("bad argument"); return -1; }
-  hipSetDevice(c->device);
+  PN_ON_DEVICE(c);
   const long long in_stride = (long long)n_frames * PN_FRAME;
   for (int f = 0; f < n_frames; f++)
     if (fg_frame(c, d_speech + (size_t)f * PN_FRAME, d_noisy + (size_t)f * PN_FRAME, in_stride,
@@ -162,7 +163,7 @@ extern "C" int pn_featgen_process_i16_files(pn_featgen *c, const int16_t *d_spee
 extern "C" int pn_featgen_process_host_i16_files(pn_featgen *c, const int16_t *h_speech, const int16_t *h_noisy,
                                                  int n_frames, float *h_records, int16_t *h_test_pcm) {
   if (!c || !h_speech || !h_noisy || !h_records || n_frames < 0) { pn_set_error("bad argument"); return -1; }
-  hipSetDevice(c->device);
+  PN_ON_DEVICE(c);
   const size_t n_in = (size_t)c->B * n_frames * PN_FRAME, n_rec = (size_t)c->B * n_frames * 138;
   int16_t *d_sp = NULL, *d_no = NULL, *d_pcm = NULL; float *d_rec = NULL;
   int rc = -1;

@@ -68,6 +68,43 @@ def synth_batch(n_streams, n_frames, first_stream=0, base_seed=BASE_SEED):
     return np.stack([synth_stream(first_stream + s, n_frames, base_seed) for s in range(n_streams)])
 
 
+def _synth_chunk(args):
+    lo, hi, n_frames, base_seed = args
+    return np.stack([synth_stream(s, n_frames, base_seed) for s in range(lo, hi)])
+
+
+def synth_batch_parallel(n_streams, n_frames, first_stream=0, base_seed=BASE_SEED, workers=None):
+    """synth_batch on worker PROCESSES (fresh interpreters fed over pipes: safe in a process that already
+    initialised HIP and independent of what __main__ is): the long-horizon parity tests need 1024 distinct streams x
+    1000 frames (~0.1 s each on one core)."""
+    import os
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+    workers = max(1, min(workers, 64, n_streams // 4))
+    if workers == 1:
+        return synth_batch(n_streams, n_frames, first_stream, base_seed)
+    step = (n_streams + workers - 1) // workers
+    jobs = [(first_stream + lo, first_stream + min(lo + step, n_streams)) for lo in range(0, n_streams, step)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from percepnet_amd import synth; "
+            "sys.stdout.buffer.write(synth._synth_chunk((%d, %d, %d, %d)).tobytes())")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+
+    def run(job):
+        out = subprocess.run([sys.executable, "-c", code % (root, job[0], job[1], n_frames, base_seed)],
+                             stdout=subprocess.PIPE, check=True, env=env).stdout
+        return np.frombuffer(out, np.int16).reshape(job[1] - job[0], n_frames * FRAME)
+
+    with ThreadPoolExecutor(len(jobs)) as ex:
+        return np.concatenate(list(ex.map(run, jobs)))
+
+
 def synth_batch_fast(n_streams, n_frames, seed=0):
     """Cheap bench filler for very large batches: a small pool of distinct streams (all three
     kinds) tiled to n_streams with per-stream sample rotation.  Parity never uses this."""

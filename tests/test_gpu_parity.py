@@ -241,7 +241,7 @@ def test_full_size_properties_65536_streams(model, oracle):
     independent and tile/XCD placement never changes a result (identical input => bit-identical
     output wherever the stream sits), plus an oracle check on the 16 distinct inputs."""
     import torch
-    B, T, P = 65536, 3, 16
+    B, T, P = 65536, 10, 16         # the pipeline delays audio by 5 frames: output frames 5.. carry signal
     base = synth.synth_batch(P, T)
     idx = np.arange(B) % P
     dev = torch.device("cuda:0")
@@ -259,6 +259,7 @@ def test_full_size_properties_65536_streams(model, oracle):
         assert np.array_equal(g, g[:P][idx])
         outs.append((o[:P], g[:P]))
     ro, rg = _oracle_batch(oracle, base)
+    assert np.abs(ro[:, 5 * 480:]).max() > 1000          # the compared PCM is real signal, not the pipeline's zeros
     for t in range(1, T):
         d = np.abs(outs[t][0].astype(np.int32) - ro[:, (t - 1) * 480:t * 480].astype(np.int32)).max()
         assert d <= PCM_TOL_LSB
@@ -354,7 +355,7 @@ def test_multi_frame_device_api(model, oracle):
 
 
 @pytest.mark.parametrize("mode", ["mfma", "f16"])
-def test_placement_invariance_across_grid_stride_rounds(model, mode):
+def test_placement_invariance_across_grid_stride_rounds(model, oracle, mode):
     """8195 streams built from 7 distinct ones, 14 frames (the history ring wraps): the front-end kernel's 256 blocks
     take several grid-stride rounds, the last one ragged.  Identical streams must produce bit-identical features,
     spectra-derived gains and PCM wherever they sit — catches anything that leaks from one round (or one
@@ -364,12 +365,19 @@ def test_placement_invariance_across_grid_stride_rounds(model, mode):
     idx = np.arange(B) % K
     pcm = base[idx]
     ctx = api.Context(model, B, nn_mode=api.NN_MFMA if mode == "mfma" else api.NN_MFMA_F16)
+    ro, rg, rf, rs = oracle.run_batch(base)      # ... and the 7 base streams must also be the ORACLE's
+    pcm_tol, gr_tol = (PCM_TOL_LSB, GR_TOL) if mode == "mfma" else (F16_PCM_TOL_LSB, F16_GR_TOL)
     for t in range(T):
         frame = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])
         out = np.empty_like(frame)
         gr = np.empty((B, 68), np.float32)
         assert ctx.L.pn_process_host_i16(ctx.h, frame.ctypes.data, out.ctypes.data, gr.ctypes.data) == 0
         feat, sil = ctx.read_features()
+        assert np.array_equal(feat[:K].view(np.uint32), rf[:, t].view(np.uint32)), (t, "features vs oracle")
+        assert np.array_equal(sil[:K], rs[:, t]), (t, "silence vs oracle")
+        assert np.abs(gr[:K] - rg[:, t]).max() <= gr_tol, (t, "g/r vs oracle")
+        if t > 0:
+            assert np.abs(out[:K].astype(np.int32) - ro[:, (t - 1) * 480:t * 480].astype(np.int32)).max() <= pcm_tol, (t, "pcm vs oracle")
         for k in range(K):
             m = idx == k
             f = feat[m].view(np.uint32)

@@ -169,3 +169,21 @@ def test_train_oracle_bit_exact_vs_compiled_reference(blob, oracle, tmp_path):
         assert np.array_equal(rp, op), p
         # the reference's other by-product: test_input.pcm == the noisy input
         assert np.array_equal(np.fromfile(d / "test_input.pcm", np.int16), no)
+
+
+def test_batched_oracle_is_bit_identical(oracle):
+    """pno_run_pcm_batch (groups of streams share each sweep over the weights, groups spread over host threads) is the
+    oracle the long-horizon GPU tests use: PCM, g/r tap, features and silence flags must equal the single-stream
+    functions bit for bit, for full and ragged groups, every stream kind, and any thread count."""
+    S, T = 23, 24
+    pcm = synth.synth_batch(S, T)                     # kinds: voiced, loud (3), bursts (7), two-tone (13)
+    want = [oracle.run_pcm(pcm[s]) for s in range(S)]
+    wf = [oracle.features(pcm[s].astype(np.float32) / np.float32(32768)) for s in range(S)]
+    for group, threads in ((8, 3), (5, 1), (32, 2), (1, 8)):
+        out, gr, feat, sil = oracle.run_batch(pcm, group=group, threads=threads)
+        for s in range(S):
+            assert np.array_equal(out[s], want[s][0]), (group, s)
+            assert np.array_equal(gr[s].view(np.uint32), want[s][1].view(np.uint32)), (group, s)
+            assert np.array_equal(feat[s].view(np.uint32), wf[s][0].view(np.uint32)), (group, s)
+            assert np.array_equal(sil[s], wf[s][1]), (group, s)
+    assert (sil[3] == 0).any() and sil[7].any()       # both silence branches are in the sample
