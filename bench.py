@@ -34,12 +34,22 @@ PEAK_HBM_TBS = 8.0
 
 def _cpu_worker(args):
     """Time the CPU baseline on one core for ~budget seconds: percepNet_run semantics
-    (main.cpp:30-39) on in-memory PCM, 100-frame (1 s of audio) chunks."""
-    kind, budget, seed = args
+    (main.cpp:30-39) on in-memory PCM, 100-frame (1 s of audio) chunks.  pin: logical CPU to bind to, or None."""
+    kind, budget, seed, pin = args
+    if pin is not None:
+        try:
+            os.sched_setaffinity(0, {pin})
+        except OSError:
+            pass
     from percepnet_amd import synth, weights
     from oracle import oracle as orc
     blob = weights.default_blob(1234)
-    eng = orc.Reference(blob) if kind == "reference" else orc.Oracle(blob)
+    if kind == "reference":
+        eng = orc.Reference(blob)
+    elif kind == "reference_avx2":
+        eng = orc.Reference(blob, so=orc.REF_AVX2_SO)
+    else:
+        eng = orc.Oracle(blob)
     pcm = synth.synth_stream(seed, 100)
     eng.run_pcm(pcm[:480 * 5], want_gr=False)     # touch code + weights once
     n = 0
@@ -52,10 +62,30 @@ def _cpu_worker(args):
             return n, dt
 
 
-def cpu_baseline(budget=10.0):
+def physical_cores():
+    """One logical CPU per physical core of this process's affinity mask (first SMT sibling)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+    seen, picks = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            picks.append(c)
+    return picks
+
+
+def cpu_baseline(budget=8.0):
     """Reference CPU path (oracle/_ref = the untouched reference sources built with the README
     flags; falls back to the C restatement, kind "port", if that .so did not travel) timed on
-    this host: first one process alone, then one process per logical CPU, ~budget seconds each."""
+    this host, SURVEY §8(d): (1) one process alone; (2) one process per PHYSICAL core, each pinned to its core —
+    the headline `value`; (3) the unpinned one-process-per-logical-CPU pool (the "as shipped" fan-out of
+    utils/run.sh) for context; (4) footnote: the -mavx2 -mfma -U__AVX__ build on one core."""
     import multiprocessing as mp
     from oracle import oracle as orc
     from percepnet_amd import weights
@@ -63,26 +93,51 @@ def cpu_baseline(budget=10.0):
     weights.default_blob(1234)                     # create the on-disk cache before forking
     kind = "reference" if os.path.exists(orc.REF_SO) else "port"
     try:
-        cores = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    n1, t1 = _cpu_worker((kind, min(budget, 4.0), 0))
+        logical = os.cpu_count() or 1
+    phys = physical_cores()
+    n1, t1 = _cpu_worker((kind, min(budget, 3.0), 0, None))
+    avx = None
+    if kind == "reference" and os.path.exists(orc.REF_AVX2_SO):
+        na, ta = _cpu_worker(("reference_avx2", 2.0, 0, None))
+        avx = na / ta
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(kind, budget, s) for s in range(cores)], chunksize=1)
+    with ctx.Pool(len(phys)) as pool:
+        res = pool.map(_cpu_worker, [(kind, budget, s, c) for s, c in enumerate(phys)], chunksize=1)
+    fps_phys = sum(n / dt for n, dt in res)
+    frames_phys = sum(n for n, _ in res)
+    with ctx.Pool(logical) as pool:
+        res2 = pool.map(_cpu_worker, [(kind, budget * 0.6, s, None) for s in range(logical)], chunksize=1)
+    fps_all = sum(n / dt for n, dt in res2)
     wall = time.perf_counter() - t0
-    fps_all = sum(n / dt for n, dt in res)
-    print(f"[bench] cpu baseline: kind={kind} cores={cores} one-core {n1 / t1:.1f} fps, "
-          f"all-core {fps_all:.1f} fps, pool wall {wall:.1f} s", file=sys.stderr, flush=True)
+    print(f"[bench] cpu baseline: kind={kind} one-core {n1 / t1:.1f} fps, {len(phys)} pinned physical cores "
+          f"{fps_phys:.1f} fps, {logical} unpinned logical CPUs {fps_all:.1f} fps, pools wall {wall:.1f} s",
+          file=sys.stderr, flush=True)
     return {
-        "value": round(fps_all / 100.0, 3), "unit": "real-time 48 kHz streams (all host CPUs)",
-        "frames_per_s": round(fps_all, 1), "frames_per_s_one_core": round(n1 / t1, 1),
-        "cores": cores, "kind": kind,
-        "sample": f"{cores} processes (one synthetic stream each) x ~{budget:.0f} s wall, "
-                  f"{sum(n for n, _ in res)} stream-frames in total, 100-frame chunks; "
-                  f"plus one process alone for the one-core figure",
+        "value": round(fps_phys / 100.0, 3), "unit": "real-time 48 kHz streams (one pinned process per physical host core)",
+        "frames_per_s": round(fps_phys, 1), "frames_per_s_one_core": round(n1 / t1, 1),
+        "cores": len(phys), "kind": kind,
+        "sample": f"{len(phys)} processes, one synthetic stream each, pinned one per physical core, ~{budget:.0f} s wall, "
+                  f"{frames_phys} stream-frames in total, 100-frame chunks; plus one process alone for the one-core figure",
+        "unpinned_all_logical_cpus": {"cores": logical, "frames_per_s": round(fps_all, 1), "streams": round(fps_all / 100.0, 3)},
+        "best_effort_avx2_fma_one_core_fps": None if avx is None else round(avx, 1),
+        "note": "all-core figures are DRAM-bound: every process re-streams its own 32 MB of weights per frame",
     }
+
+
+KERNEL_SOURCES = ("pn_nn.hip", "pn_nn_common.h", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_context.cpp")
+
+
+def kernels_snapshot():
+    """Identity of the kernels a profile was taken with: sha256 over the kernel sources (first 12 hex digits).
+    tools/summarize_prof.py stamps it into profiles/*_pmc_per_launch.csv; a CSV from other kernels is refused."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "percepnet_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def pmc_traffic_bytes(streams):
@@ -90,22 +145,59 @@ def pmc_traffic_bytes(streams):
     this same command (profiles/*_pmc_per_launch.csv; FETCH_SIZE and WRITE_SIZE are collected in
     separate --pmc runs, both in KB).  Per MI355X_MICROARCH.md the gfx950 FETCH_SIZE counts 64 B
     per 128-B request for 16 B/lane streaming loads, so it is doubled; WRITE_SIZE is used as is
-    (it equals the algorithmic store bytes exactly).  None if no profile matches this batch size."""
+    (it equals the algorithmic store bytes exactly).  Only a CSV stamped with the CURRENT kernels' snapshot id is
+    accepted (a profile of other kernels says nothing about this run): -> (bytes | None, source note)."""
     import csv, glob
+    snap = kernels_snapshot()
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_launch.csv")))
-    if not files:
-        return None, None
+    fresh = [f for f in files if open(f).readline().strip() == f"# kernels_snapshot={snap}"]
+    if not fresh:
+        return None, f"no PMC profile of kernels snapshot {snap} under profiles/ (tools/gpu_profile.sh + tools/summarize_prof.py)"
     grid = f"grid={((streams + 127) // 128 + 7) // 8 * 8 * 16 * 256}"
     fetch = write = None
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith("pn_gru_mfma_p_kernel") and r["kernel"].endswith(grid):
+    rows = [l for l in open(fresh[-1]) if not l.startswith("#")]
+    for r in csv.DictReader(rows):
+        if r["kernel"].startswith("pn_gru_mfma") and r["kernel"].endswith(grid):
             if r["counter"] == "FETCH_SIZE":
                 fetch = float(r["avg"]) * 1024 * 2
             elif r["counter"] == "WRITE_SIZE":
                 write = float(r["avg"]) * 1024
     if fetch is None or write is None:
-        return None, None
-    return fetch + write, os.path.basename(files[-1])
+        return None, f"{os.path.basename(fresh[-1])} has no FETCH/WRITE rows for {grid}"
+    return fetch + write, os.path.basename(fresh[-1])
+
+
+def measure_parity(ctx, frames, pool_pcm, out, torch):
+    """BASELINE metric part (iii), MEASURED on this run's own batch, outside the timed region: the context is reset,
+    the same W+K frames are run again and the first P batch slots (the pool's P distinct, unrotated streams) are
+    captured every frame and compared with the CPU oracle on the same PCM.  Also checks that the replay ends on the
+    same output as the timed run (the kernels are deterministic)."""
+    from oracle.oracle import Oracle
+    from percepnet_amd import weights
+    P, T = pool_pcm.shape[0], len(frames)
+    B = ctx.n_streams
+    last_timed = out.clone()
+    dev = out.device
+    g = torch.empty((B, 68), dtype=torch.float32, device=dev)
+    acc_o = torch.empty((T, P, 480), dtype=torch.int16, device=dev)
+    acc_g = torch.empty((T, P, 68), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.reset()
+    for t in range(T):
+        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), g.data_ptr())
+        acc_o[t].copy_(out[:P]); acc_g[t].copy_(g[:P])
+    torch.cuda.synchronize()
+    replay_identical = bool(torch.equal(out, last_timed))
+    ro, rg, _, _ = Oracle(weights.default_blob(1234)).run_batch(pool_pcm, want_feat=False)
+    got = acc_o[1:].permute(1, 0, 2).reshape(P, (T - 1) * 480).cpu().numpy().astype("int32")
+    d = abs(got - ro.astype("int32"))
+    dg = abs(acc_g.permute(1, 0, 2).cpu().numpy() - rg)
+    return {"max_abs_delta_vs_cpu_ref_lsb": int(d.max()), "pcm_samples_differing": int((d != 0).sum()),
+            "pcm_samples_checked": int(d.size), "max_abs_delta_gr": float(dg.max()),
+            "sample": f"the {P} distinct pool streams (batch slots 0..{P - 1}) x all {T} frames of this run vs the CPU oracle "
+                      f"(oracle/percepnet_oracle.c, bit-exact to the compiled reference)",
+            "replay_of_timed_run_bit_identical": replay_identical,
+            "long_horizon": "tests/test_gpu_longrun.py: 1024 streams x 1000 frames and 256 sampled of 65536 x 1000 frames"}
 
 
 def main():
@@ -116,6 +208,7 @@ def main():
     ap.add_argument("--streams", type=int, default=65536, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
+    ap.add_argument("--no-parity", action="store_true", help="skip the measured max|delta| vs the CPU oracle")
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
     ap.add_argument("--fp16", action="store_true",
                     help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: <=3 LSB)")
@@ -124,32 +217,31 @@ def main():
                     help="testing aid on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(a.gpus, world)
+    from percepnet_amd import sharding
+    rank, local_rank, world = sharding.launched_world()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
+        sys.exit(sharding.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()          # before HIP is initialised in this process (fork safety)
 
     import numpy as np
     import torch
-    import torch.distributed as dist
     from percepnet_amd import api, synth, weights
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
     if a.share_gpu:
         local_rank = 0
+        os.environ["PN_ALLOW_SHARED_DEVICE"] = "1"
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+    dist = sharding.init_ranks(a.backend, a.gpus, dev)       # refuses WORLD_SIZE != --gpus
+    n_gpus = world
 
     B, K, W = a.streams, a.steps, a.warmup
     print(f"[bench] rank {rank}/{world} B={B} K={K} W={W}", file=sys.stderr, flush=True)
@@ -161,9 +253,10 @@ def main():
                       stream=stream.cuda_stream)
 
     # synthetic input, resident in HBM: a pool of 64 distinct streams (voiced / bursts+silence /
-    # two-tone) tiled over the batch with per-replica sample rotation
+    # two-tone / loud) tiled over the batch with per-replica sample rotation
     P = min(B, 64)
-    pool = torch.from_numpy(synth.synth_batch(P, T, base_seed=synth.BASE_SEED + 7919 * rank)).to(dev)
+    pool_np = synth.synth_batch(P, T, base_seed=synth.BASE_SEED + 7919 * rank)
+    pool = torch.from_numpy(pool_np).to(dev)
     idx = torch.arange(B, device=dev) % P
     rot = (torch.arange(B, device=dev) // P) * 37
     frames = []
@@ -179,31 +272,23 @@ def main():
     def step(t):
         ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), gr_buf.data_ptr() if gr_buf is not None else None)
 
-    # The context runs on its own non-blocking HIP stream, the inputs above were produced by torch kernels on torch's
-    # stream: without this the warm-up frames can be read while their last rows are still being written
-    # (run-to-run noise in the last few thousand streams; seen with the faster fp16 variant).
+    def before_timed():
+        if not a.no_profile:
+            ctx.reset_profile()
+            ctx.set_profiling(True)
+    step.before_timed = before_timed
+
+    # The inputs above were produced by torch kernels; the context launches on torch's current stream, so the order is
+    # implicit — the synchronise only keeps input generation out of the warm-up.
     torch.cuda.synchronize()
     print(f"[bench] inputs resident ({T} frames x {B} streams), state {ctx.device_bytes() / 2**30:.2f} GiB",
           file=sys.stderr, flush=True)
-    for t in range(W):
-        step(t)
-    torch.cuda.synchronize()
-    if not a.no_profile:
-        ctx.reset_profile()
-        ctx.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(W, T):
-        step(t)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = sharding.timed_steps(dist, step, W, K, torch.cuda.synchronize)
     ctx.set_profiling(False)
-    from percepnet_amd.sharding import aggregate_throughput
-    fps, dt = aggregate_throughput(dist if world > 1 else None, B * K, dt)   # SUM frames / MAX time
+    props = torch.cuda.get_device_properties(local_rank)
+    label = f"cuda:{local_rank} {props.name} pci {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+    rep = sharding.gather_report(dist, B * K, dt, label)      # SUM frames / MAX time; refuses duplicate devices
+    fps, dt = rep["fps"], rep["seconds"]
 
     kt = {} if a.no_profile else ctx.kernel_times()
     checksum = int(out.to(torch.int64).abs().sum().item())     # keeps the result live / sanity
@@ -212,6 +297,9 @@ def main():
         _np.save(os.environ["PN_BENCH_DUMP"], out.cpu().numpy())
 
     if rank == 0:
+        parity = None
+        if not a.no_parity and not a.strict:
+            parity = measure_parity(ctx, frames, pool_np, out, torch)
         res = {
             "metric": "real-time 48 kHz streams (10 ms frames), whole job",
             "value": round(fps / 100.0, 1),
@@ -221,8 +309,6 @@ def main():
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 GEMM operands, f32 accumulate/state/DSP" if a.fp16 else "f32", "data": "synthetic",
-            "max_abs_delta_vs_cpu_ref_lsb": ("<=3 (fp16 variant, tests/test_gpu_parity.py::test_fp16_variant_tolerance)" if a.fp16
-                                             else "<=1 (tests/test_gpu_parity.py; STRICT mode 0)"),
             "config": {
                 "workload": ("configs[2]: 65536 concurrent 48 kHz streams per MI355X, fp32 network as MFMA GEMM"
                              if (B == 65536 and not a.fp16) else
@@ -230,12 +316,18 @@ def main():
                              f"{B} concurrent 48 kHz streams per MI355X (configs[1] = 1024)"),
                 "streams_per_gpu": B, "frame_samples": FRAME, "nn_mode": "strict" if a.strict else ("mfma_f16" if a.fp16 else "mfma_f32"),
                 "weights": "torch.manual_seed(1234) default-init PercepNet in nnet_data.h layout",
-                "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective",
+                "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective",
                 "io": "int16 PCM resident in HBM",
             },
+            "ranks": rep["ranks"],
+            "per_gpu_frames_per_s": [r["fps"] for r in rep["ranks"]],
             "state_bytes_per_gpu": ctx.device_bytes(),
             "checksum": checksum,
         }
+        if parity is not None:
+            res["max_abs_delta_vs_cpu_ref_lsb"] = parity["max_abs_delta_vs_cpu_ref_lsb"]
+            res["max_abs_delta_gr"] = parity["max_abs_delta_gr"]
+            res["parity"] = parity
         if kt:
             per = {k: {"ms_avg": round(v[0] / max(v[1], 1), 4), "launches": v[1]} for k, v in kt.items()}
             res["kernels"] = per
@@ -250,7 +342,7 @@ def main():
                     "kernel": ("pn_gru_f16_kernel" if a.fp16 else "pn_gru_mfma_p_kernel") + " (512->512 reset-after GRU step, 4 launches per frame)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None if a.fp16 else traffic,
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
                     "algorithmic_bytes_per_launch": 3 * B * 512 * 4 + 2 * 512 * 1536 * 4,   # x, h read; h' written; W,U once
                     "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4),
                     "whole_pipeline_tflops": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2),
@@ -262,7 +354,8 @@ def main():
         print(json.dumps(res), flush=True)
     ctx.close()
     model.close()
-    if world > 1:
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

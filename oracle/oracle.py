@@ -13,6 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libpercepnet_ref.so")
+REF_AVX2_SO = os.path.join(HERE, "_ref", "libpercepnet_ref_avx2.so")   # "best-effort CPU" footnote build, timing only
 
 c_f = ctypes.POINTER(ctypes.c_float)
 c_s = ctypes.POINTER(ctypes.c_short)
@@ -28,7 +29,7 @@ def build(force=False):
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
             os.path.join(HERE, "percepnet_oracle.c")):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO)):
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO) or not os.path.exists(REF_AVX2_SO)):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
 
 
@@ -147,9 +148,9 @@ def ref_available():
 class Reference:
     """The reference itself (untouched sources compiled by oracle/Makefile `ref`)."""
 
-    def __init__(self, blob):
+    def __init__(self, blob, so=None):
         assert ref_available(), "oracle/_ref/libpercepnet_ref.so not built"
-        self.lib = ctypes.CDLL(REF_SO)
+        self.lib = ctypes.CDLL(so or REF_SO)
         L = self.lib
         L.ref_load_weights.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.ref_create.restype = ctypes.c_void_p

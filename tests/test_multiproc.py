@@ -1,8 +1,9 @@
-"""world_size-2 CPU (gloo) test of the multi-GPU launch logic bench.py uses: streams are sharded
-across ranks with no data-path collective; ranks only meet at a barrier and a MAX all-reduce of the
-wall time, and rank 0 aggregates value = (sum of stream-frames over ranks) / max time."""
+"""world_size-2 CPU (gloo) tests of the multi-GPU launch path.  bench.py keeps everything around its GPU step in
+percepnet_amd/sharding.py — self-launch of the ranks (spawn_ranks), joining and REFUSING a wrong world (init_ranks),
+the barrier-bracketed timed region (timed_steps), SUM-frames / MAX-time aggregation and the per-rank report with its
+duplicate-device check (gather_report) — and this file runs exactly that code end to end with a CPU step."""
+import json
 import os
-import socket
 import subprocess
 import sys
 import textwrap
@@ -12,46 +13,75 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = textwrap.dedent("""
     import os, sys, time, json
     sys.path.insert(0, %r)
-    import numpy as np, torch, torch.distributed as dist
-    from percepnet_amd import synth
-    from percepnet_amd.sharding import shard_streams, aggregate_throughput
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    total = 10                                  # global stream ids 0..9, ragged over 2 ranks
-    mine = shard_streams(total, rank, world)
+    import numpy as np
+    from percepnet_amd import synth, sharding
+    expected = int(sys.argv[1]); share = sys.argv[2] == "share"
+    dist = sharding.init_ranks("gloo", expected)
+    rank, local_rank, world = sharding.launched_world()
+    total = 10                                  # global stream ids 0..9, ragged over the ranks
+    mine = sharding.shard_streams(total, rank, world)
     pcm = np.stack([synth.synth_stream(s, 2) for s in mine])     # each rank touches only its shard
-    dist.barrier()
-    t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dt = time.perf_counter() - t0
-    dist.barrier()
-    fps, dt_max = aggregate_throughput(dist, len(mine) * 2, dt)
-    ids = [None] * world
-    dist.all_gather_object(ids, list(mine))
+    calls = []
+    def step(t):
+        calls.append(t); time.sleep(0.02 * (rank + 1))           # rank 1 is the slow one
+    step.before_timed = lambda: calls.append("timed")
+    dt = sharding.timed_steps(dist, step, 2, 3, lambda: None)
+    rep = sharding.gather_report(dist, len(mine) * 3, dt, "cpu:0" if share else "cpu:%%d" %% local_rank, {"ids": list(mine)})
     if rank == 0:
-        print(json.dumps({"ids": ids, "fps": fps, "dt_max": dt_max, "frames": total * 2}))
-    dist.destroy_process_group()
+        print(json.dumps({"rep": rep, "calls": calls, "dt0": dt}))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 """)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def test_two_rank_sharding_and_aggregation(tmp_path):
+def _launch(tmp_path, n, expected, share="own"):
+    from percepnet_amd import sharding
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
-        env=env, capture_output=True, text=True, timeout=300)
+    cmd = [sys.executable, "-c",
+           "import sys; sys.path.insert(0, %r); from percepnet_amd import sharding; "
+           "sys.exit(sharding.spawn_ranks(%d, %r, [%r, %r], timeout=240))" % (ROOT, n, str(script), str(expected), share)]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+
+def test_two_rank_launch_timing_and_report(tmp_path):
+    out = _launch(tmp_path, 2, 2)
     assert out.returncode == 0, out.stderr[-2000:]
-    import json
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
-    flat = sorted(x for part in r["ids"] for x in part)
-    assert flat == list(range(10))                       # every stream owned by exactly one rank
-    assert abs(len(r["ids"][0]) - len(r["ids"][1])) <= 1  # balanced
-    assert r["dt_max"] >= 0.09                            # MAX over ranks, not rank 0's own time
-    assert abs(r["fps"] - r["frames"] / r["dt_max"]) < 1e-6
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rep = r["rep"]
+    assert rep["n_ranks"] == 2 and [x["rank"] for x in rep["ranks"]] == [0, 1]
+    assert [x["device"] for x in rep["ranks"]] == ["cpu:0", "cpu:1"]          # who ran where is part of the report
+    flat = sorted(i for x in rep["ranks"] for i in x["ids"])
+    assert flat == list(range(10))                                            # every stream owned by exactly one rank
+    assert abs(len(rep["ranks"][0]["ids"]) - len(rep["ranks"][1]["ids"])) <= 1
+    assert r["calls"] == [0, 1, "timed", 2, 3, 4]                             # W warm-up steps, hook, exactly K timed
+    slow = max(x["seconds"] for x in rep["ranks"])
+    assert rep["seconds"] >= 0.11 and abs(rep["seconds"] - slow) < 1e-3        # MAX over ranks (rank 1 sleeps 3 x 40 ms)
+    assert abs(rep["fps"] - 30 / rep["seconds"]) < 1e-6 * rep["fps"] + 1e-3    # SUM of stream-frames / MAX time
+    assert abs(r["dt0"] - rep["seconds"]) < 0.03                              # the closing barrier holds rank 0 for rank 1
+
+
+def test_wrong_world_is_refused(tmp_path):
+    out = _launch(tmp_path, 2, 3)               # asked for 3 ranks, launched 2: never report a world that did not run
+    assert out.returncode != 0
+    assert "refusing to report" in out.stderr
+
+
+def test_two_ranks_on_one_device_are_refused(tmp_path):
+    out = _launch(tmp_path, 2, 2, share="share")
+    assert out.returncode != 0
+    assert "same device" in out.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts 2 ranks itself; without a GPU each rank stops at the
+    no-fallback check — which shows both were launched through torch.distributed.run."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check (the GPU version is tests/test_gpu_bench.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]

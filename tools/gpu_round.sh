@@ -1,0 +1,17 @@
+#!/bin/bash
+# One gpurun call = the whole evidence set for a snapshot: GPU tests, the bench line, configs[1], fp16, the profile.
+#   tools/gpu_round.sh <tag> [tests|notests]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02a}; MODE=${2:-tests}
+O=$R/gpurun_out; mkdir -p $O
+cd $R
+if [ "$MODE" = "tests" ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/pytest_$TAG.log 2>&1; echo "pytest rc=$?" >> $O/pytest_$TAG.log
+  tail -5 $O/pytest_$TAG.log
+fi
+timeout 600 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err; tail -c 600 $O/bench_$TAG.err
+timeout 300 python bench.py --streams 1024 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_${TAG}_1024.json 2>> $O/bench_$TAG.err
+timeout 300 python bench.py --fp16 --no-cpu-baseline > $O/bench_${TAG}_fp16.json 2>> $O/bench_$TAG.err
+timeout 900 bash tools/gpu_profile.sh $TAG > $O/profile_$TAG.log 2>&1
+head -c 1500 $O/bench_$TAG.json; echo
+ls $O/prof_summary
