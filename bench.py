@@ -248,7 +248,11 @@ def main():
     T = K + W
     blob = weights.default_blob(1234)
     model = api.Model(blob)
-    stream = torch.cuda.current_stream()
+    # one explicit stream for torch AND the context: torch's default stream has handle 0, which pn_ctx_create reads as
+    # "create your own non-blocking stream" — unordered against torch's kernels
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx = api.Context(model, B, device=local_rank, nn_mode=api.NN_STRICT if a.strict else (api.NN_MFMA_F16 if a.fp16 else api.NN_MFMA),
                       stream=stream.cuda_stream)
 
@@ -278,8 +282,8 @@ def main():
             ctx.set_profiling(True)
     step.before_timed = before_timed
 
-    # The inputs above were produced by torch kernels; the context launches on torch's current stream, so the order is
-    # implicit — the synchronise only keeps input generation out of the warm-up.
+    # The inputs above were produced by torch kernels on `stream`, the context launches on the same stream: ordered.
+    # The synchronise only keeps input generation out of the warm-up.
     torch.cuda.synchronize()
     print(f"[bench] inputs resident ({T} frames x {B} streams), state {ctx.device_bytes() / 2**30:.2f} GiB",
           file=sys.stderr, flush=True)

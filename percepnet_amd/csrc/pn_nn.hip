@@ -54,11 +54,12 @@
 #endif
 
 // =============================== STRICT kernels ==================================================
-// W in the reference layout [K][ncols] (nnet_data.h); thread = (stream blockIdx.y, neuron).
+// W in the reference layout [K][ncols] (nnet_data.h); thread = (stream, neuron); the stream index is folded into
+// grid.x (block = nbx * stream + neuron block) because grid.y stops at 65535 and a batch may be larger.
 __global__ void pn_dense_strict_kernel(PnSegs A, const float *__restrict__ W, const float *__restrict__ bias,
                                        int N, int act, const float *__restrict__ tansig, float *__restrict__ out,
-                                       int ldo) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+                                       int ldo, int nbx) {
+  const int m = blockIdx.x / nbx, n = (blockIdx.x - m * nbx) * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float acc = bias[n];
   int koff = 0;
@@ -72,8 +73,8 @@ __global__ void pn_dense_strict_kernel(PnSegs A, const float *__restrict__ W, co
 
 __global__ void pn_gru_strict_kernel(PnSegs X, const float *__restrict__ h_old, const float *__restrict__ W,
                                      const float *__restrict__ U, const float *__restrict__ b, int N, int act,
-                                     const float *__restrict__ tansig, float *__restrict__ h_new) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+                                     const float *__restrict__ tansig, float *__restrict__ h_new, int nbx) {
+  const int m = blockIdx.x / nbx, n = (blockIdx.x - m * nbx) * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int st = 3 * N;
   const float *h = h_old + (size_t)m * N;
@@ -940,8 +941,8 @@ int pn_dense_nt(int N) { return (N % 128 == 0) ? 4 : 2; }
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows) {
   if (strict) {
-    dim3 grid((N + 63) / 64, n_rows);
-    hipLaunchKernelGGL(pn_dense_strict_kernel, grid, dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo);
+    const int nbx = (N + 63) / 64;
+    hipLaunchKernelGGL(pn_dense_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo, nbx);
     return;
   }
   const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
@@ -972,8 +973,8 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
                    float *h_new, int n_rows) {
   if (strict) {
-    dim3 grid((N + 63) / 64, n_rows);
-    hipLaunchKernelGGL(pn_gru_strict_kernel, grid, dim3(64), 0, st, X, h_old, W, U, b, N, act, tansig, h_new);
+    const int nbx = (N + 63) / 64;
+    hipLaunchKernelGGL(pn_gru_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, X, h_old, W, U, b, N, act, tansig, h_new, nbx);
     return;
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels

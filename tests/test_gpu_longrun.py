@@ -47,9 +47,19 @@ def _record(name, stats):
     print(json.dumps(stats))
 
 
+def shared_stream(dev):
+    """A torch stream to run BOTH torch's kernels and the context's launches on (so they are ordered).  torch's default
+    stream has handle 0, which pn_ctx_create reads as "create your own stream": never pass that."""
+    import torch
+    ts = torch.cuda.Stream(dev)
+    assert ts.cuda_stream != 0
+    return ts
+
+
 def run_long(ctx, frame_of, T, rows, dev):
     """Advance ctx by T frames; frame_of(t) -> int16 device tensor [B,480].  Returns, for the batch rows `rows`
-    (device index tensor or None = all): out int16 [R,(T-1)*480], gr [R,T,68], feat [R,T,70], sil [R,T] (numpy)."""
+    (device index tensor or None = all): out int16 [R,(T-1)*480], gr [R,T,68], feat [R,T,70], sil [R,T] (numpy).
+    Must be called inside `with torch.cuda.stream(ts)` of the stream the context was created on."""
     import torch
     B = ctx.n_streams
     R = B if rows is None else int(rows.numel())
@@ -110,12 +120,14 @@ def test_configs1_1024_streams_1000_frames_every_stream_vs_oracle(model, oracle)
     t0 = time.time()
     ref = oracle.run_batch(pcm, group=8)
     t_oracle = time.time() - t0
-    d_pcm = torch.from_numpy(pcm).to(dev)
-    ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=torch.cuda.current_stream().cuda_stream)
-    t0 = time.time()
-    got = run_long(ctx, lambda t: d_pcm[:, t * 480:(t + 1) * 480].contiguous(), T, None, dev)
-    t_gpu = time.time() - t0
-    ctx.close()
+    ts = shared_stream(dev)
+    with torch.cuda.stream(ts):
+        d_pcm = torch.from_numpy(pcm).to(dev)
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=ts.cuda_stream)
+        t0 = time.time()
+        got = run_long(ctx, lambda t: d_pcm[:, t * 480:(t + 1) * 480].contiguous(), T, None, dev)
+        t_gpu = time.time() - t0
+        ctx.close()
     st = compare("configs1_1024x1000", got, ref, {
         "config": "configs[1]: 1024 concurrent streams, fp32 MFMA network, every stream vs the CPU oracle",
         "synth_s": round(t_synth, 1), "oracle_s": round(t_oracle, 1), "gpu_s": round(t_gpu, 1)})
@@ -149,19 +161,21 @@ def test_configs2_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle)
     ref = oracle.run_batch(pool, group=8)
     t_oracle = time.time() - t0
     slots, idx, rot = sample_layout(B, P)
-    d_pool = torch.from_numpy(pool).to(dev)
-    d_idx = torch.from_numpy(idx).to(dev)
-    ar = (torch.arange(480, device=dev)[None, :] + torch.from_numpy(rot).to(dev)[:, None]) % 480
-    rows = torch.from_numpy(slots).to(dev)
+    ts = shared_stream(dev)
+    with torch.cuda.stream(ts):
+        d_pool = torch.from_numpy(pool).to(dev)
+        d_idx = torch.from_numpy(idx).to(dev)
+        ar = (torch.arange(480, device=dev)[None, :] + torch.from_numpy(rot).to(dev)[:, None]) % 480
+        rows = torch.from_numpy(slots).to(dev)
 
-    def frame_of(t):
-        return torch.gather(d_pool[:, t * 480:(t + 1) * 480][d_idx], 1, ar).contiguous()
+        def frame_of(t):
+            return torch.gather(d_pool[:, t * 480:(t + 1) * 480][d_idx], 1, ar).contiguous()
 
-    ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=torch.cuda.current_stream().cuda_stream)
-    t0 = time.time()
-    got = run_long(ctx, frame_of, T, rows, dev)
-    t_gpu = time.time() - t0
-    ctx.close()
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=ts.cuda_stream)
+        t0 = time.time()
+        got = run_long(ctx, frame_of, T, rows, dev)
+        t_gpu = time.time() - t0
+        ctx.close()
     compare("configs2_65536x1000_sample256", got, ref, {
         "config": "configs[2]: 65536 concurrent streams, fp32 MFMA network, 256 distinct sampled streams vs the CPU oracle",
         "sample_slots_first_last": [int(slots[0]), int(slots[-1])], "oracle_s": round(t_oracle, 1), "gpu_s": round(t_gpu, 1)})
