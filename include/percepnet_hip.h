@@ -120,6 +120,15 @@ int pn_ctx_read_features_dev(pn_ctx *ctx, float *d_feat, int32_t *d_silence);
    on the context's RNN state.  Advances only the network's state (conv FIFOs, GRUs), like calling the reference's
    compute_rnn on an RNNState directly; the DSP state and frame counter of pn_process_* are untouched. */
 int pn_ctx_compute_rnn_host(pn_ctx *ctx, const float *h_feat, float *h_gr);
+/* Load / store the network state of every stream from / to host arrays in the reference's RNNState layout
+   (nnet_data.h:28-38): conv1 [n_streams][4*128] and conv2 [n_streams][2*512] = the live part of the FIFOs, oldest
+   frame first (nnet.cpp:191-199); gru1, gru2, gru3, gru_gb [n_streams][512]; gru_rb [n_streams][128].  NULL
+   arrays are skipped.  Synchronous.  (Checkpoint/resume of the recurrent state, and what the exported
+   compute_rnn(RNNState*, ...) uses.) */
+int pn_ctx_set_rnn_state_host(pn_ctx *ctx, const float *conv1, const float *conv2, const float *gru1, const float *gru2,
+                              const float *gru3, const float *gru_gb, const float *gru_rb);
+int pn_ctx_get_rnn_state_host(pn_ctx *ctx, float *conv1, float *conv2, float *gru1, float *gru2, float *gru3,
+                              float *gru_gb, float *gru_rb);
 
 /* ---- per-kernel timing (HIP events on the context's stream) ------------------------------- */
 /* When enabled, every launch of the named kernel families is bracketed by events. */
@@ -181,6 +190,11 @@ float rnnoise_process_frame_c(DenoiseState *st, float *out, const float *in, FIL
 int rnnoise_train_c(int argc, char **argv);            /* train(), rnnoise.h:66 */
 RNNModel *rnnoise_model_from_file_c(FILE *f);
 void rnnoise_model_free_c(RNNModel *model);
+/* compute_rnn (rnnoise.h:68, rnn.cpp:42-81), also exported under its C++-mangled name
+   _Z11compute_rnnP8RNNStatePfS1_PKf: one network step on a caller-owned RNNState (host arrays); gains[34],
+   strengths[34], input[70].  The state is uploaded to a cached batch-of-one context, advanced on the GPU (network mode
+   PERCEPNET_STRICT=1|0, device PERCEPNET_DEVICE) and written back, so the caller sees the reference's semantics. */
+void rnnoise_compute_rnn_c(RNNState *rnn, float *gains, float *strengths, const float *input);
 
 #ifdef __cplusplus
 }

@@ -64,4 +64,20 @@ typedef struct RNNModel {
   const DenseLayer *fc_rb;
 } RNNModel;
 
+/* Per-stream network state exactly as the reference declares it (src/nnet_data.h:28-38): host arrays owned by the
+   caller (rnnoise_init callocs them, denoise.cpp:268-274): conv FIFOs of kernel_size*nb_inputs floats of which the
+   first (kernel_size-1)*nb_inputs are live (oldest frame first, nnet.cpp:191-199), GRU states of nb_neurons.
+   compute_rnn(RNNState*, ...) (rnnoise.h:68, rnn.cpp:42) is exported by libpercepnet_hip with this record. */
+typedef struct RNNState {
+  const RNNModel *model;
+  float *first_conv1d_state;
+  float *second_conv1d_state;
+  float *gru1_state;
+  float *gru2_state;
+  float *gru3_state;
+  float *gb_gru_state;
+  float *rb_gru_state;
+  float convout_buf[PN_CONV_DIM * 3];
+} RNNState;
+
 #endif

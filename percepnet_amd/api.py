@@ -68,6 +68,10 @@ def load_library():
     L.pn_ctx_read_features.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_read_features_dev.argtypes = [_vp, _vp, _vp]
     L.pn_ctx_compute_rnn_host.argtypes = [_vp, _vp, _vp]
+    L.pn_ctx_set_rnn_state_host.argtypes = [_vp] * 8
+    L.pn_ctx_get_rnn_state_host.argtypes = [_vp] * 8
+    L.pn_ctx_debug_copy.restype = ctypes.c_longlong
+    L.pn_ctx_debug_copy.argtypes = [_vp, ctypes.c_int, _vp, ctypes.c_longlong]
     L.pn_ctx_set_profiling.argtypes = [_vp, ctypes.c_int]
     L.pn_kernel_name.restype = ctypes.c_char_p
     L.pn_kernel_name.argtypes = [ctypes.c_int]
@@ -211,6 +215,28 @@ class Context:
         gr = np.empty((self.n_streams, 68), np.float32)
         self._chk(self.L.pn_ctx_compute_rnn_host(self.h, feat.ctypes.data, gr.ctypes.data))
         return gr
+
+    RNN_STATE_SHAPES = (("conv1", 4 * 128), ("conv2", 2 * 512), ("gru1", 512), ("gru2", 512), ("gru3", 512),
+                        ("gru_gb", 512), ("gru_rb", 128))
+
+    def get_rnn_state(self):
+        """-> {name: float32 [n_streams, n]} in the reference's RNNState layout (nnet_data.h:28-38)."""
+        st = {k: np.empty((self.n_streams, n), np.float32) for k, n in self.RNN_STATE_SHAPES}
+        self._chk(self.L.pn_ctx_get_rnn_state_host(self.h, *[st[k].ctypes.data for k, _ in self.RNN_STATE_SHAPES]))
+        return st
+
+    def set_rnn_state(self, st):
+        arrs = [np.ascontiguousarray(st[k], dtype=np.float32).reshape(self.n_streams, n) if k in st else None
+                for k, n in self.RNN_STATE_SHAPES]
+        self._chk(self.L.pn_ctx_set_rnn_state_host(self.h, *[a.ctypes.data if a is not None else None for a in arrs]))
+
+    def debug_copy(self, which, n_floats):
+        """Internal device buffer `which` (see pn_ctx_debug_copy in percepnet_hip.h) -> float32[n_floats] (tests/tools)."""
+        buf = np.empty(n_floats, np.float32)
+        n = self.L.pn_ctx_debug_copy(self.h, which, buf.ctypes.data, buf.nbytes)
+        if n < 0:
+            raise PercepNetError(_err(self.L))
+        return buf[:n // 4]
 
     def set_profiling(self, on):
         self._chk(self.L.pn_ctx_set_profiling(self.h, 1 if on else 0))

@@ -17,6 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpercepnet_hip.so")
 RUN = os.path.join(LIBDIR, "percepnet_run")
+RELINKED = os.path.join(LIBDIR, "percepNet_run_relinked")    # reference src/main.cpp, untouched, linked against LIB
+REFERENCE_SRC = os.environ.get("PERCEPNET_REFERENCE_SRC", "/root/reference/src")
 SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_f16.hip", "pn_targets.hip", "pn_context.cpp",
            "pn_featgen.cpp", "rnnoise_compat.cpp"]
 # percepnet_run.cpp / percepnet_featgen.cpp (the CLIs) are linked separately against the library
@@ -29,6 +31,24 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+# The kernels carry two workarounds for codegen hazards of this exact toolchain; a different
+# hipcc is allowed but announced, and the context-creation self-test (pn_ctx_create) is what guards the results.
+EXPECTED_HIP = "7.2"
+
+
+def toolchain_info(hipcc):
+    try:
+        out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError as e:
+        return f"hipcc --version failed: {e}"
+    ver = next((l.split(":", 1)[1].strip() for l in out.splitlines() if l.startswith("HIP version")), "?")
+    if not ver.startswith(EXPECTED_HIP):
+        print(f"[percepnet_amd.build] WARNING: hipcc reports HIP {ver}; the kernels were validated with HIP {EXPECTED_HIP}.x "
+              f"(MFMA-drain and loop back-edge hazards, DESIGN.md): run the GPU parity tests before trusting this build",
+              file=sys.stderr, flush=True)
+    return out.strip()
 
 
 def _stale(target, deps):
@@ -87,10 +107,22 @@ def build(force=False, verbose=True):
         cli, exe = os.path.join(CSRC, name + ".cpp"), os.path.join(LIBDIR, name)
         if os.path.exists(cli) and (force or _stale(exe, [cli, LIB])):
             cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", cli, "-o", exe, "-L" + LIBDIR,
-                   "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN"]
+                   "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+    # INTEGRATION.md level 1, built for real: the reference's own UNTOUCHED main.cpp (the percepNet_run CLI) compiled
+    # where it lies and linked against this library instead of the reference's objects.  Only possible where
+    # /root/reference exists (this container); the binary travels to the GPU box like the .so (tests/test_gpu_parity.py).
+    ref_main = os.path.join(REFERENCE_SRC, "main.cpp")
+    if os.path.exists(ref_main) and (force or _stale(RELINKED, [ref_main, LIB])):
+        cmd = ["g++", "-std=c++11", "-O3", "-w", "-I" + REFERENCE_SRC, ref_main, "-o", RELINKED, "-L" + LIBDIR,
+               "-lpercepnet_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with open(os.path.join(LIBDIR, "BUILD_INFO.txt"), "w") as f:
+        f.write(toolchain_info(hipcc) + "\nflags: " + " ".join(FLAGS) + "\n")
     return LIB
 
 

@@ -600,6 +600,43 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
   return 0;
 }
 
+// ---- network state <-> host arrays in the reference's RNNState layout (nnet_data.h:28-38) ---------------------------
+// The conv FIFOs are rings here: the ks-1 previous layer inputs, oldest first, live in slots (tn+1+j) % ks, j = 0..ks-2
+// (launch_rnn reads panels (tn+1+j) % ks for j = 0..ks-1, the last one being the slot the current step writes).
+// The GRU states are ping-pong pairs: buffer tn & 1 holds the state the next step reads.
+static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2, float *const gru[4], float *rb) {
+  PN_ON_DEVICE(c);
+  if (pipe_drain(c)) return -1;
+  if (c->nn_mode == PN_NN_MFMA_F16) { pn_set_error("RNN state load/store is not available in the fp16-operand mode (shadow buffers)"); return -1; }
+  const size_t B = c->B, Bp = c->Bp; const int64_t t = c->tn;
+  const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+  auto cp2d = [&](float *host, size_t hpitch, float *dev, size_t dpitch, size_t width) -> hipError_t {
+    return to_device ? hipMemcpy2DAsync(dev, dpitch * 4, host, hpitch * 4, width * 4, B, kind, c->stream)
+                     : hipMemcpy2DAsync(host, hpitch * 4, dev, dpitch * 4, width * 4, B, kind, c->stream);
+  };
+  if (conv1) for (int j = 0; j < 4; j++)
+    PN_HIP_CHECK(cp2d(conv1 + j * 128, 4 * 128, c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128, 128, 128));
+  if (conv2) for (int j = 0; j < 2; j++)
+    PN_HIP_CHECK(cp2d(conv2 + j * 512, 2 * 512, c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512, 512, 512));
+  for (int i = 0; i < 4; i++)
+    if (gru[i]) PN_HIP_CHECK(cp2d(gru[i], 512, c->gru[i] + (size_t)(t & 1) * Bp * 512, 512, 512));
+  if (rb) PN_HIP_CHECK(cp2d(rb, 128, c->rb + (size_t)(t & 1) * Bp * 128, 128, 128));
+  PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int pn_ctx_set_rnn_state_host(pn_ctx *c, const float *conv1, const float *conv2, const float *gru1, const float *gru2,
+                                         const float *gru3, const float *gru_gb, const float *gru_rb) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  float *g[4] = {(float *)gru1, (float *)gru2, (float *)gru3, (float *)gru_gb};
+  return rnn_state_copy(c, true, (float *)conv1, (float *)conv2, g, (float *)gru_rb);
+}
+extern "C" int pn_ctx_get_rnn_state_host(pn_ctx *c, float *conv1, float *conv2, float *gru1, float *gru2, float *gru3,
+                                         float *gru_gb, float *gru_rb) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  float *g[4] = {gru1, gru2, gru3, gru_gb};
+  return rnn_state_copy(c, false, conv1, conv2, g, gru_rb);
+}
+
 // Debug tap (tests/tools only): copy an internal device buffer to the host.
 // which: 0 feat[B][128], 1 c1ring[5][B][128], 2 c2ring[3][B][512], 3 c2out[B][512],
 //        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68].  Returns the byte count.

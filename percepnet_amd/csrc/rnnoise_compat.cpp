@@ -11,6 +11,8 @@
 #include "../../include/percepnet_hip.h"
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 
 // link-time model of the reference (denoise.cpp:49-51): generated nnet_data.cpp defines it.
 // Weak: a caller may instead pass a model explicitly or set PERCEPNET_MODEL=<file.pnw>.
@@ -21,6 +23,7 @@ struct DenoiseState {
   pn_ctx *ctx;
   pn_model *model;
   float gr[68];
+  int failed;
 };
 #define DS_MAGIC 0x504e4453u
 
@@ -29,6 +32,11 @@ int rnnoise_get_size() { return (int)sizeof(DenoiseState); }
 // rnnoise_init (denoise.cpp:259-280): zero state, bind the model.  Returns 0; on failure the
 // state is left inert (process_frame then outputs silence) and pn_last_error() says why —
 // the reference has no error path at all here.
+// Still returns 0 (existing callers ignore the value and the reference cannot fail here), but an inert state is never
+// silent: one line on stderr says why no audio will come out.
+static int env_device() { const char *d = getenv("PERCEPNET_DEVICE"); return d ? atoi(d) : 0; }
+static int env_mode() { const char *s = getenv("PERCEPNET_STRICT"); return (s && atoi(s)) ? PN_NN_STRICT : PN_NN_MFMA; }
+
 int rnnoise_init(DenoiseState *st, RNNModel *model) {
   memset(st, 0, sizeof(*st));
   st->magic = DS_MAGIC;
@@ -37,13 +45,18 @@ int rnnoise_init(DenoiseState *st, RNNModel *model) {
   else if (const char *path = getenv("PERCEPNET_MODEL")) {
     FILE *f = fopen(path, "rb");
     if (f) { st->model = pn_model_from_file(f); fclose(f); }
+    else fprintf(stderr, "percepnet_hip: rnnoise_init: cannot open PERCEPNET_MODEL=%s\n", path);
   }
-  if (!st->model) return 0;
-  int dev = 0;
-  if (const char *d = getenv("PERCEPNET_DEVICE")) dev = atoi(d);
-  int mode = PN_NN_MFMA;
-  if (const char *s = getenv("PERCEPNET_STRICT")) mode = atoi(s) ? PN_NN_STRICT : PN_NN_MFMA;
-  st->ctx = pn_ctx_create(st->model, dev, 1, mode, NULL);
+  if (!st->model) {
+    fprintf(stderr, "percepnet_hip: rnnoise_init: no model (pass an RNNModel, link a generated nnet_data.cpp defining "
+                    "percepnet_model_orig, or set PERCEPNET_MODEL=<file.pnw>)%s%s: the state is INERT, "
+                    "rnnoise_process_frame will output silence\n", pn_last_error()[0] ? ": " : "", pn_last_error());
+    return 0;
+  }
+  st->ctx = pn_ctx_create(st->model, env_device(), 1, env_mode(), NULL);
+  if (!st->ctx)
+    fprintf(stderr, "percepnet_hip: rnnoise_init: %s: the state is INERT, rnnoise_process_frame will output silence "
+                    "(this library has no CPU fallback)\n", pn_last_error());
   return 0;
 }
 
@@ -66,9 +79,44 @@ float rnnoise_process_frame(DenoiseState *st, float *out, const float *in, FILE 
   if (!st || st->magic != DS_MAGIC || !st->ctx) { if (out) memset(out, 0, PN_FRAME_SIZE * sizeof(float)); return 0; }
   float tmp[PN_FRAME_SIZE];
   memcpy(tmp, in, sizeof(tmp));
-  pn_process_host_f32(st->ctx, tmp, out, st->gr);
+  if (pn_process_host_f32(st->ctx, tmp, out, st->gr) != 0) {     // HIP error: defined output, no stale tap, one message
+    memset(out, 0, PN_FRAME_SIZE * sizeof(float));
+    if (!st->failed) { st->failed = 1; fprintf(stderr, "percepnet_hip: rnnoise_process_frame: %s\n", pn_last_error()); }
+    return 0;
+  }
   if (f_feature) { fwrite(st->gr, sizeof(float), 34, f_feature); fwrite(st->gr + 34, sizeof(float), 34, f_feature); }
   return 0;
+}
+
+// compute_rnn (rnnoise.h:68, rnn.cpp:42-81) on a caller-owned RNNState: exported with the reference's prototype (the
+// compiler emits _Z11compute_rnnP8RNNStatePfS1_PKf).  The state lives in the caller's host arrays as in the reference;
+// each call uploads it to a batch-of-one context cached per model, runs the ten layers on the GPU and writes the new
+// state back.  Correct but launch- and PCIe-bound by construction — batched callers use pn_ctx_compute_rnn_host.
+static std::mutex g_rnn_mu;
+static std::map<const RNNModel *, std::pair<pn_model *, pn_ctx *>> g_rnn_ctx;
+
+void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *input) {
+  if (!rnn || !rnn->model || !gains || !strengths || !input) return;
+  std::lock_guard<std::mutex> lk(g_rnn_mu);
+  auto it = g_rnn_ctx.find(rnn->model);
+  if (it == g_rnn_ctx.end()) {
+    pn_model *m = pn_model_from_rnnmodel(rnn->model);
+    pn_ctx *c = m ? pn_ctx_create(m, env_device(), 1, env_mode(), NULL) : NULL;
+    if (!c) fprintf(stderr, "percepnet_hip: compute_rnn: %s (no CPU fallback: outputs are zero)\n", pn_last_error());
+    it = g_rnn_ctx.emplace(rnn->model, std::make_pair(m, c)).first;
+  }
+  pn_ctx *c = it->second.second;
+  float gr[68];
+  if (!c ||
+      pn_ctx_set_rnn_state_host(c, rnn->first_conv1d_state, rnn->second_conv1d_state, rnn->gru1_state, rnn->gru2_state,
+                                rnn->gru3_state, rnn->gb_gru_state, rnn->rb_gru_state) ||
+      pn_ctx_compute_rnn_host(c, input, gr) ||
+      pn_ctx_get_rnn_state_host(c, rnn->first_conv1d_state, rnn->second_conv1d_state, rnn->gru1_state, rnn->gru2_state,
+                                rnn->gru3_state, rnn->gb_gru_state, rnn->rb_gru_state)) {
+    memset(gains, 0, 34 * sizeof(float)); memset(strengths, 0, 34 * sizeof(float));
+    return;
+  }
+  memcpy(gains, gr, 34 * sizeof(float)); memcpy(strengths, gr + 34, 34 * sizeof(float));
 }
 
 // rnnoise_model_from_file / rnnoise_model_free are declared by the reference (rnnoise.h:62-64)
@@ -124,6 +172,7 @@ void rnnoise_destroy_c(DenoiseState *st) { rnnoise_destroy(st); }
 float rnnoise_process_frame_c(DenoiseState *st, float *out, const float *in, FILE *f) { return rnnoise_process_frame(st, out, in, f); }
 RNNModel *rnnoise_model_from_file_c(FILE *f) { return rnnoise_model_from_file(f); }
 void rnnoise_model_free_c(RNNModel *m) { rnnoise_model_free(m); }
+void rnnoise_compute_rnn_c(RNNState *rnn, float *gains, float *strengths, const float *input) { compute_rnn(rnn, gains, strengths, input); }
 }
 
 // ---- train(), rnnoise.h:66 / denoise.cpp:603-787: the body of the `percepNet` binary -----------------

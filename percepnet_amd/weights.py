@@ -131,13 +131,16 @@ def random_layers(seed, scale=None):
     return out
 
 
-def pack_blob(layers):
+def pack_blob(layers, acts=None):
     """Serialise to the PNW1 container: magic, u32 n_layers, then per layer
     ``u32 kind, nb_inputs, nb_neurons, kernel_size, activation, reset_after`` followed by the
-    float32 arrays bias, input_weights[, recurrent_weights]."""
+    float32 arrays bias, input_weights[, recurrent_weights].  acts: optional {layer name: activation code}
+    overriding the PercepNet topology's activations (the known-answer tests embed the reference's toy layers)."""
     parts = [MAGIC, struct.pack("<I", len(LAYERS))]
     for name, kind, nin, nn_, ks, act in LAYERS:
         d = layers[name]
+        if acts and name in acts:
+            act = acts[name]
         parts.append(struct.pack("<6I", kind, nin, nn_, ks, act, 1 if kind == KIND_GRU else 0))
         nb = 6 * nn_ if kind == KIND_GRU else nn_
         assert d["bias"].size == nb, name

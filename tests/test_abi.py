@@ -32,6 +32,7 @@ def test_reference_mangled_symbols_exported(lib):
               "_Z14rnnoise_createP8RNNModel", "_Z15rnnoise_destroyP12DenoiseState",
               "_Z21rnnoise_process_frameP12DenoiseStatePfPKfP8_IO_FILE",
               "_Z23rnnoise_model_from_fileP8_IO_FILE", "_Z18rnnoise_model_freeP8RNNModel",
+              "_Z11compute_rnnP8RNNStatePfS1_PKf",       # void compute_rnn(RNNState*, float*, float*, const float*), rnnoise.h:68
               "_Z5trainiPPc"]:          # int train(int, char**), rnnoise.h:66
         assert hasattr(lib, n), n
 
@@ -76,3 +77,24 @@ def test_header_is_plain_c_and_a_c_caller_links(lib, blob, tmp_path):
         assert "no context" in r.stdout and "HIP" in r.stdout
     else:
         assert "process rc=0" in r.stdout
+
+
+def test_relinked_reference_cli_is_never_silently_inert(lib, blob, tmp_path):
+    """The reference's untouched main.cpp linked against this library (lib/percepNet_run_relinked): when no model or no
+    usable GPU is there, rnnoise_init leaves the state inert — the reference has no error path, main.cpp ignores return
+    values — but says so on stderr instead of producing a silent all-zero file without a word."""
+    import subprocess
+    import numpy as np
+    import torch
+    if not os.path.exists(build.RELINKED):
+        pytest.skip("needs /root/reference at build time")
+    (tmp_path / "a.pcm").write_bytes((np.arange(480 * 4) % 1000).astype(np.int16).tobytes())
+    env = {k: v for k, v in os.environ.items() if k != "PERCEPNET_MODEL"}
+    r = subprocess.run([build.RELINKED, "a.pcm", "o.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "INERT" in r.stderr and "no model" in r.stderr
+    if not torch.cuda.is_available():
+        (tmp_path / "m.pnw").write_bytes(blob)
+        r = subprocess.run([build.RELINKED, "a.pcm", "o.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                           env=dict(env, PERCEPNET_MODEL=str(tmp_path / "m.pnw")))
+        assert r.returncode == 0 and "INERT" in r.stderr and "no CPU fallback" in r.stderr
+        assert not np.fromfile(tmp_path / "o.pcm", np.int16).any()

@@ -139,10 +139,10 @@ def sample_layout(B, P):
     tile and grid-stride-round boundaries included) carry the P distinct streams unrotated; every other slot carries
     pool stream (slot % P) with its samples rotated inside each frame, as bench.py fills its batch."""
     rng = np.random.default_rng(7)
-    slots = np.unique(np.concatenate([[0, 1, 127, 128, 255, 256, 4095, 4096, 4097, B - 1, B - 2, B - 129],
-                                      rng.choice(B, size=2 * P, replace=False)]))[:P]
-    slots = np.sort(slots)
-    assert slots.size == P
+    fixed = np.array([0, 1, 127, 128, 255, 256, 4095, 4096, 4097, B - 129, B - 2, B - 1])
+    rest = np.setdiff1d(rng.permutation(B)[:2 * P], fixed, assume_unique=False)
+    slots = np.sort(np.concatenate([fixed, rng.permutation(rest)[:P - fixed.size]]))
+    assert slots.size == P and np.unique(slots).size == P and slots[-1] == B - 1
     idx = np.arange(B) % P
     rot = ((np.arange(B) // P) * 37 + 11) % 480
     idx[slots] = np.arange(P)

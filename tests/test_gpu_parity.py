@@ -417,3 +417,147 @@ def test_pipelined_host_path_matches_synchronous(model):
     ctx.host_wait()
     assert np.array_equal(h_out[0].numpy(), ref[0][0])
     ctx.close()
+
+
+def _zero_layers():
+    return {name: {"bias": np.zeros(6 * nn_ if kind == weights.KIND_GRU else nn_, np.float32),
+                   "input_weights": np.zeros(nin * ks * nn_ * (3 if kind == weights.KIND_GRU else 1), np.float32),
+                   **({"recurrent_weights": np.zeros(nn_ * 3 * nn_, np.float32)} if kind == weights.KIND_GRU else {})}
+            for name, kind, nin, nn_, ks, act in weights.LAYERS}
+
+
+@pytest.mark.parametrize("mode", [api.NN_STRICT, api.NN_MFMA])
+def test_reference_known_answers_through_the_hip_kernels(golden_dir, mode):
+    """The reference's own gtest vectors (tests/testnnet.cpp:19-66 + tests/nnet_data_test.h -> tests/golden/nnet_kat.json,
+    toy 2->3 dense / conv1d(k=3) / GRU layers, eps 1e-5) run through the PRODUCTION kernels — STRICT and MFMA — by
+    zero-embedding each toy layer in the corresponding PercepNet-shaped layer (extra inputs, taps and neurons carry
+    zero weights, so they add exact zeros to every chain) and feeding it the test's constant 0.5 inputs through
+    layers with zero weights and a 0.5 bias."""
+    import json
+    k = {n: np.array(v, np.float32) for n, v in json.load(open(os.path.join(golden_dir, "nnet_kat.json"))).items()}
+    SIG, TANH, LIN = weights.ACT_SIGMOID, weights.ACT_TANH, weights.ACT_LINEAR
+    feat = np.zeros((1, 70), np.float32); feat[0, :2] = 0.5
+    Bp = 256
+
+    def ctx_for(layers, acts):
+        m = api.Model(weights.pack_blob(layers, acts))
+        return m, api.Context(m, 1, nn_mode=mode)
+
+    # compute_dense: fc 2->3 sigmoid embedded in fc 70->128
+    L = _zero_layers()
+    W = L["fc"]["input_weights"].reshape(70, 128); W[:2, :3] = k["fc_weights"].reshape(2, 3)
+    L["fc"]["bias"][:3] = k["fc_bias"]
+    m, ctx = ctx_for(L, {"fc": SIG})
+    ctx.compute_rnn(feat)
+    fc_out = ctx.debug_copy(1, 5 * Bp * 128).reshape(5, Bp, 128)[0, 0, :3]      # c1ring slot tn%5 = 0
+    assert np.abs(fc_out - k["fc_output"]).max() < 1e-5, fc_out
+    ctx.close(); m.close()
+
+    # compute_conv1d: 2 -> 3, kernel 3, sigmoid, embedded in conv1 128 -> 512 kernel 5 (its 3 newest taps)
+    L = _zero_layers()
+    L["fc"]["bias"][:2] = 0.5                                                     # fc: linear, output = [.5, .5, 0 ...]
+    W = L["conv1"]["input_weights"].reshape(5, 128, 512); W[2:, :2, :3] = k["conv1_weights"].reshape(3, 2, 3)
+    L["conv1"]["bias"][:3] = k["conv1_bias"]
+    m, ctx = ctx_for(L, {"fc": LIN, "conv1": SIG})
+    for push, row in ((1, None), (2, 0), (3, 1)):                                 # testnnet.cpp:37-48
+        ctx.compute_rnn(feat)
+        out = ctx.debug_copy(2, 3 * Bp * 512).reshape(3, Bp, 512)[(push - 1) % 3, 0, :3]
+        if row is not None:
+            assert np.abs(out - k["conv1_output"][3 * row:3 * row + 3]).max() < 1e-5, (push, out)
+    ctx.close(); m.close()
+
+    # compute_gru: 2 -> 3 reset-after tanh, embedded in gru1 512 -> 512; its input [.5, .5, 0 ...] comes from conv2's bias
+    L = _zero_layers()
+    L["conv2"]["bias"][:2] = 0.5
+    W = L["gru1"]["input_weights"].reshape(512, 3, 512); W[:2, :, :3] = k["gru1_weights"].reshape(2, 3, 3)
+    U = L["gru1"]["recurrent_weights"].reshape(512, 3, 512); U[:3, :, :3] = k["gru1_recurrent_weights"].reshape(3, 3, 3)
+    b = L["gru1"]["bias"].reshape(2, 3, 512); b[:, :, :3] = k["gru1_bias"].reshape(2, 3, 3)
+    m, ctx = ctx_for(L, {"fc": LIN, "conv1": LIN, "conv2": LIN, "gru1": TANH})
+    for step in range(3):
+        ctx.compute_rnn(feat)
+        st = ctx.get_rnn_state()["gru1"][0]
+        assert np.abs(st[:3] - k["gru1_output"][3 * step:3 * step + 3]).max() < 1e-5, (step, st[:3])
+        assert not st[3:].any()                                                   # the padding neurons stay at exactly 0
+    ctx.close(); m.close()
+
+
+def test_rnn_state_roundtrip_and_compute_rnn_symbol(blob, oracle):
+    """pn_ctx_get/set_rnn_state_host move the network state in the reference's RNNState layout (nnet_data.h:28-38), and
+    the exported compute_rnn(RNNState*, gains, strengths, input) (rnnoise.h:68; mangled like the reference's) advances a
+    caller-owned host state exactly like the reference's: STRICT mode bit-identical to the oracle, step by step."""
+    rng = np.random.default_rng(5)
+    T = 7
+    feats = (rng.standard_normal((T, 70)) * 0.7).astype(np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    ref = np.zeros((T, 68), np.float32)
+    st = oracle.lib.pno_create(oracle.model)
+    for t in range(T):
+        oracle.lib.pno_compute_rnn(st, ref[t, :34].ctypes.data_as(fp), ref[t, 34:].ctypes.data_as(fp), feats[t].ctypes.data_as(fp))
+    oracle.lib.pno_destroy(st)
+
+    # (1) state save / restore through the batched API: run 4 steps, move the state to a fresh context, continue
+    m = api.Model(blob)
+    a = api.Context(m, 1, nn_mode=api.NN_STRICT)
+    for t in range(4):
+        assert np.array_equal(a.compute_rnn(feats[t][None])[0], ref[t])
+    saved = a.get_rnn_state()
+    b = api.Context(m, 1, nn_mode=api.NN_STRICT)
+    b.compute_rnn(feats[0][None])                 # put b's rings at a different phase first
+    b.set_rnn_state(saved)
+    for t in range(4, T):
+        assert np.array_equal(b.compute_rnn(feats[t][None])[0], ref[t]), t
+    a.close(); b.close(); m.close()
+
+    # (2) the reference's entry point on a caller-owned RNNState
+    L = ctypes.CDLL(api.LIB_PATH)
+    class RNNState(ctypes.Structure):
+        _fields_ = [("model", ctypes.c_void_p)] + [(n, fp) for n in ("c1", "c2", "g1", "g2", "g3", "gb", "rb")] + \
+                   [("convout_buf", ctypes.c_float * 1536)]
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pnw") as f:
+        f.write(blob); f.flush()
+        libc = ctypes.CDLL(None)
+        libc.fopen.restype = ctypes.c_void_p; libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        libc.fclose.argtypes = [ctypes.c_void_p]
+        fh = libc.fopen(f.name.encode(), b"rb")
+        L.rnnoise_model_from_file_c.restype = ctypes.c_void_p; L.rnnoise_model_from_file_c.argtypes = [ctypes.c_void_p]
+        rm = L.rnnoise_model_from_file_c(fh); libc.fclose(fh)
+    assert rm
+    arrs = [np.zeros(n, np.float32) for n in (5 * 128, 3 * 512, 512, 512, 512, 512, 128)]   # rnnoise_init's callocs (denoise.cpp:268-274)
+    rs = RNNState(rm, *[x.ctypes.data_as(fp) for x in arrs])
+    fn = getattr(L, "_Z11compute_rnnP8RNNStatePfS1_PKf")
+    fn.restype = None; fn.argtypes = [ctypes.POINTER(RNNState), fp, fp, fp]
+    os.environ["PERCEPNET_STRICT"] = "1"
+    try:
+        for t in range(T):
+            g = np.zeros(34, np.float32); r = np.zeros(34, np.float32)
+            fn(ctypes.byref(rs), g.ctypes.data_as(fp), r.ctypes.data_as(fp), feats[t].ctypes.data_as(fp))
+            assert np.array_equal(np.concatenate([g, r]), ref[t]), t
+    finally:
+        del os.environ["PERCEPNET_STRICT"]
+    assert arrs[2].any() and arrs[0][:512].any()          # the caller's arrays really carry the state
+
+
+def test_relinked_reference_cli(blob, oracle, tmp_path):
+    """INTEGRATION.md level 1 for real: the reference's UNTOUCHED src/main.cpp, compiled where it lies and linked
+    against libpercepnet_hip.so (percepnet_amd/build.py -> lib/percepNet_run_relinked), run as `percepNet_run in out`
+    with the model from PERCEPNET_MODEL: out.pcm and ./feature_test.raw against the oracle."""
+    import subprocess
+    from percepnet_amd import build
+    if not os.path.exists(build.RELINKED):
+        pytest.skip("lib/percepNet_run_relinked was not built (needs /root/reference at build time)")
+    (tmp_path / "m.pnw").write_bytes(blob)
+    a = synth.synth_stream(3, 30)
+    (tmp_path / "a.pcm").write_bytes(a.tobytes())
+    env = dict(os.environ, PERCEPNET_MODEL=str(tmp_path / "m.pnw"))
+    r = subprocess.run([build.RELINKED, "a.pcm", "ao.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "INERT" not in r.stderr
+    ao = np.fromfile(tmp_path / "ao.pcm", np.int16); tap = np.fromfile(tmp_path / "feature_test.raw", np.float32).reshape(-1, 68)
+    ro, rg = oracle.run_pcm(a)
+    assert ao.size == 29 * 480 and np.abs(ao.astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+    assert np.abs(ro).max() > 1000
+    assert tap.shape == (30, 68) and np.abs(tap - rg).max() <= GR_TOL
+    r = subprocess.run([build.RELINKED, "a.pcm", "as.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(env, PERCEPNET_STRICT="1"))
+    assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "as.pcm", np.int16), ro)      # bit-exact in STRICT
