@@ -178,6 +178,7 @@ int pn_featgen_run_files(int device, int n_jobs, const char *const *speech_paths
 
 const char *pn_last_error(void);
 const char *pn_version(void);
+int pn_device_count(void);                   /* usable HIP devices (0 when there is none) */
 
 /* ---- reference frame-engine interface, extern "C" spelling -------------------------------- */
 /* (the C++-mangled rnnoise_* symbols with the reference's exact prototypes are exported too) */

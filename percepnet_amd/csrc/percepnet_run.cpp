@@ -1,47 +1,42 @@
 // percepnet_run — the reference's `percepNet_run <noisy.pcm> <out.pcm>` CLI (src/main.cpp:11-44) on
 // top of libpercepnet_hip's batched C-ABI, extended to N file pairs processed as N concurrent
-// streams.  Same I/O contract per stream: raw little-endian int16 mono 48 kHz
-// in; (frames-1)*480 samples out (first output frame dropped, main.cpp:37; partial tail frame
+// streams on one or several GPUs.  Same I/O contract per stream: raw little-endian int16
+// mono 48 kHz in; (frames-1)*480 samples out (first output frame dropped, main.cpp:37; partial tail frame
 // dropped, main.cpp:32-33); with a single pair ./feature_test.raw gets 68 floats per frame.
 //
-//   percepnet_run [--model model.pnw] [--strict] [--device N] in0.pcm out0.pcm [in1.pcm out1.pcm ...]
+//   percepnet_run [--model model.pnw] [--strict] [--postfilter] [--device N | --devices 0,1,..|all]
+//                 in0.pcm out0.pcm [in1.pcm out1.pcm ...]
+//
+// Multi-GPU: streams are independent, so the pairs are cut into contiguous balanced shards, one per
+// device; every device gets its own host thread, its own context (a replica of the weights and tables) and its own
+// pinned buffers, and the threads never talk to each other — the one-process counterpart of the reference's shell
+// fan-out (utils/run.sh:49,65,99).  No collective is involved.
 #include "../../include/percepnet_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
+#include <thread>
 #include <vector>
 
 extern const RNNModel percepnet_model_orig __attribute__((weak));
 
-int main(int argc, char **argv) {
-  const char *model_path = getenv("PERCEPNET_MODEL");
-  int strict = 0, device = 0, postfilter = 0, ai = 1;
-  for (; ai < argc; ai++) {
-    if (!strcmp(argv[ai], "--model") && ai + 1 < argc) model_path = argv[++ai];
-    else if (!strcmp(argv[ai], "--strict")) strict = 1;
-    else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
-    else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) device = atoi(argv[++ai]);
-    else break;
-  }
-  const int nfiles = argc - ai;
-  if (nfiles < 2 || (nfiles & 1)) {
-    fprintf(stderr, "usage: %s [--model model.pnw] [--strict] [--postfilter] [--device N] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
-    return 1;
-  }
-  const int B = nfiles / 2;
-  pn_model *m = NULL;
-  if (model_path) { FILE *f = fopen(model_path, "rb"); if (f) { m = pn_model_from_file(f); fclose(f); } }
-  else if (&percepnet_model_orig) m = pn_model_from_rnnmodel(&percepnet_model_orig);
-  if (!m) { fprintf(stderr, "no model: pass --model file.pnw (or link a generated nnet_data.cpp): %s\n", pn_last_error()); return 2; }
-  pn_ctx *cx = pn_ctx_create(m, device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
-  if (!cx) { fprintf(stderr, "pn_ctx_create: %s\n", pn_last_error()); return 3; }
+struct Shard { int device, first, count, rc; std::string err; };
+
+// One device: pairs [first, first+count) of argv-style (in, out) paths as `count` concurrent streams.
+static void run_shard(Shard *sh, const pn_model *m, char **paths, int strict, int postfilter, bool tap) {
+  const int B = sh->count;
+  auto fail = [&](int rc, const std::string &msg) { sh->rc = rc; sh->err = msg; };
+  pn_ctx *cx = pn_ctx_create(m, sh->device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
+  if (!cx) return fail(3, std::string("pn_ctx_create: ") + pn_last_error());
   if (postfilter) pn_ctx_set_postfilter(cx, 1);
   std::vector<FILE *> fin(B), fout(B);
   for (int s = 0; s < B; s++) {
-    fin[s] = fopen(argv[ai + 2 * s], "rb"); fout[s] = fopen(argv[ai + 2 * s + 1], "wb");
-    if (!fin[s] || !fout[s]) { fprintf(stderr, "cannot open %s / %s\n", argv[ai + 2 * s], argv[ai + 2 * s + 1]); return 4; }
+    const char *pi = paths[2 * (sh->first + s)], *po = paths[2 * (sh->first + s) + 1];
+    fin[s] = fopen(pi, "rb"); fout[s] = fopen(po, "wb");
+    if (!fin[s] || !fout[s]) return fail(4, std::string("cannot open ") + pi + " / " + po);
   }
-  FILE *ftap = (B == 1) ? fopen("feature_test.raw", "wb") : NULL;
+  FILE *ftap = tap ? fopen("feature_test.raw", "wb") : NULL;
   // Three rotating pinned buffer sets on the pipelined entry point: the files of frame t+1 are read while the GPU
   // works on frame t, and frame t-2's output is on the host once pn_submit_host_i16(t) has returned.
   struct Slot { int16_t *in, *out; float *gr; std::vector<char> alive; };
@@ -50,7 +45,7 @@ int main(int argc, char **argv) {
     sl.in = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
     sl.out = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
     sl.gr = (float *)pn_host_alloc((size_t)B * 68 * sizeof(float));
-    if (!sl.in || !sl.out || !sl.gr) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+    if (!sl.in || !sl.out || !sl.gr) return fail(5, pn_last_error());
     sl.alive.assign(B, 0);
   }
   std::vector<char> alive(B, 1), first(B, 1);
@@ -73,14 +68,64 @@ int main(int argc, char **argv) {
     }
     if (n_alive == 0) break;
     sl.alive = alive;
-    if (pn_submit_host_i16(cx, sl.in, sl.out, sl.gr)) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+    if (pn_submit_host_i16(cx, sl.in, sl.out, sl.gr)) return fail(5, pn_last_error());
     if (t >= 2) flush(slot[(t - 2) % 3]);
   }
-  if (pn_host_wait(cx)) { fprintf(stderr, "%s\n", pn_last_error()); return 5; }
+  if (pn_host_wait(cx)) return fail(5, pn_last_error());
   for (long u = (t >= 2 ? t - 2 : 0); u < t; u++) flush(slot[u % 3]);     // the last two frames in flight
   for (Slot &sl : slot) { pn_host_free(sl.in); pn_host_free(sl.out); pn_host_free(sl.gr); }
   for (int s = 0; s < B; s++) { fclose(fin[s]); fclose(fout[s]); }
   if (ftap) fclose(ftap);
-  pn_ctx_destroy(cx); pn_model_free(m);
-  return 0;
+  pn_ctx_destroy(cx);
+}
+
+int main(int argc, char **argv) {
+  const char *model_path = getenv("PERCEPNET_MODEL");
+  int strict = 0, postfilter = 0, ai = 1;
+  std::vector<int> devices;
+  for (; ai < argc; ai++) {
+    if (!strcmp(argv[ai], "--model") && ai + 1 < argc) model_path = argv[++ai];
+    else if (!strcmp(argv[ai], "--strict")) strict = 1;
+    else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
+    else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) devices.assign(1, atoi(argv[++ai]));
+    else if (!strcmp(argv[ai], "--devices") && ai + 1 < argc) {
+      const char *s = argv[++ai];
+      devices.clear();
+      if (!strcmp(s, "all")) { const int n = pn_device_count(); for (int d = 0; d < n; d++) devices.push_back(d); }
+      else for (const char *p = s; *p;) { devices.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') p++; else if (*p) { devices.clear(); break; } }
+      if (devices.empty()) { fprintf(stderr, "--devices: expected a comma-separated list of device ordinals or 'all' (%d device(s) visible)\n", pn_device_count()); return 1; }
+    }
+    else break;
+  }
+  if (devices.empty()) devices.push_back(0);
+  const int nfiles = argc - ai;
+  if (nfiles < 2 || (nfiles & 1)) {
+    fprintf(stderr, "usage: %s [--model model.pnw] [--strict] [--postfilter] [--device N | --devices 0,1,..|all] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
+    return 1;
+  }
+  const int B = nfiles / 2;
+  pn_model *m = NULL;
+  if (model_path) { FILE *f = fopen(model_path, "rb"); if (f) { m = pn_model_from_file(f); fclose(f); } }
+  else if (&percepnet_model_orig) m = pn_model_from_rnnmodel(&percepnet_model_orig);
+  if (!m) { fprintf(stderr, "no model: pass --model file.pnw (or link a generated nnet_data.cpp): %s\n", pn_last_error()); return 2; }
+  // contiguous balanced shards (the same rule as percepnet_amd/sharding.py: shard_streams); devices beyond the number
+  // of pairs stay idle
+  const int W = (int)devices.size() < B ? (int)devices.size() : B;
+  std::vector<Shard> shards(W);
+  for (int r = 0; r < W; r++) {
+    const int base = B / W, rem = B % W;
+    shards[r] = {devices[r], r * base + (r < rem ? r : rem), base + (r < rem ? 1 : 0), 0, ""};
+  }
+  const bool tap = B == 1;
+  if (W == 1) run_shard(&shards[0], m, argv + ai, strict, postfilter, tap);
+  else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < W; r++) th.emplace_back(run_shard, &shards[r], m, argv + ai, strict, postfilter, false);
+    for (auto &t : th) t.join();
+  }
+  int rc = 0;
+  for (const Shard &sh : shards)
+    if (sh.rc) { fprintf(stderr, "device %d (pairs %d..%d): %s\n", sh.device, sh.first, sh.first + sh.count - 1, sh.err.c_str()); if (sh.rc > rc) rc = sh.rc; }
+  pn_model_free(m);
+  return rc;
 }

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -18,7 +19,8 @@ void pn_set_error(const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char *pn_last_error(void) { return g_err; }
-extern "C" const char *pn_version(void) { return "percepnet_hip 0.1 (gfx950)"; }
+extern "C" const char *pn_version(void) { return "percepnet_hip 0.2 (gfx950)"; }
+extern "C" int pn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 // ---- models -------------------------------------------------------------------------------------------
 static const struct { int kind, nin, nn, ks; } kGeom[PN_NLAYERS] = {
@@ -207,6 +209,8 @@ static int zero_state(pn_ctx *c) {
   return 0;
 }
 
+static int nn_selftest(pn_ctx *c, const pn_model *model);
+
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
   DeviceGuard _dg(c->device);
@@ -320,6 +324,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
     }
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
+  if (nn_mode == PN_NN_MFMA && nn_selftest(c, model)) goto fail;
   return c;
 fail:
   pn_ctx_destroy(c);
@@ -446,6 +451,69 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs A = seg1(rbn, 128, 128);
     if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, NULL, 0, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B); }
+}
+
+// Known-answer self-test of the MFMA network kernels, run once per context creation (PERCEPNET_SELFTEST=0 skips it).
+// The MFMA path depends on hand-placed wait states and pinned instruction order; a toolchain that
+// schedules it differently could lose accumulator updates silently (the failure once seen hit output rows 27/31 mod
+// 32 only).  So the freshly built context runs two network steps on a fixed pseudo-random input over up to 192 rows
+// (six 32-row wave tiles, two M tiles) with the MFMA kernels and again with the reference-order STRICT kernels on
+// the same weights, and refuses to come up if any g/r output differs by more than the documented 2e-5.
+static int nn_selftest(pn_ctx *c, const pn_model *model) {
+  const char *env = getenv("PERCEPNET_SELFTEST");
+  if (env && !atoi(env)) return 0;
+  const int B_full = c->B, rows = B_full < 192 ? B_full : 192;
+  std::vector<float> feat((size_t)rows * PN_NFEAT), gr[2][2];
+  unsigned x = 12345u;
+  auto fill = [&]() { for (float &v : feat) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 8) % 2001 - 1000) * 1.5e-3f; } };
+  DevLayer saved[PN_NLAYERS]; memcpy(saved, c->L, sizeof(saved));
+  std::vector<void *> temps;
+  int rc = 0;
+  c->B = rows;
+  for (int pass = 0; pass < 2 && !rc; pass++) {        // pass 0: MFMA kernels; pass 1: STRICT kernels
+    if (pass == 1) {
+      c->nn_mode = PN_NN_STRICT;
+      for (int li = 0; li < PN_NLAYERS && !rc; li++) {
+        const PnLayerHost &H = model->L[li];
+        size_t nb, nw, nr; layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
+        void *w = NULL, *rw = NULL;
+        if (hipMalloc(&w, nw * 4) != hipSuccess || hipMemcpyAsync(w, H.w, nw * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1;
+        if (w) temps.push_back(w);
+        if (!rc && nr) { if (hipMalloc(&rw, nr * 4) != hipSuccess || hipMemcpyAsync(rw, H.rw, nr * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1; if (rw) temps.push_back(rw); }
+        c->L[li].w = (float *)w; c->L[li].rw = (float *)rw;
+      }
+    }
+    x = 12345u;
+    for (int step = 0; step < 2 && !rc; step++) {
+      fill();
+      gr[pass][step].resize((size_t)rows * 68);
+      if (hipMemcpy2DAsync(c->feat, PN_FEAT_STRIDE * 4, feat.data(), PN_NFEAT * 4, PN_NFEAT * 4, rows, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = -1; break; }
+      launch_rnn(c);
+      c->tn++;
+      if (hipMemcpyAsync(gr[pass][step].data(), c->gr, (size_t)rows * 68 * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = -1;
+    }
+    c->B = B_full;                                      // zero_state clears the whole batch
+    if (zero_state(c) || hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
+    c->B = rows;
+  }
+  c->B = B_full; c->nn_mode = PN_NN_MFMA; memcpy(c->L, saved, sizeof(saved));
+  for (void *p : temps) hipFree(p);
+  if (rc) { pn_set_error("network self-test could not run (HIP error)"); return -1; }
+  float worst = 0, spread = 0; int wrow = 0, wcol = 0;
+  for (int step = 0; step < 2; step++)
+    for (size_t i = 0; i < gr[0][step].size(); i++) {
+      const float d = fabsf(gr[0][step][i] - gr[1][step][i]);
+      if (!(d <= worst)) { worst = d; wrow = (int)(i / 68); wcol = (int)(i % 68); }     // NaN lands here too
+      spread = fmaxf(spread, fabsf(gr[1][step][i] - gr[1][step][i % 68]));
+    }
+  if (!(worst <= 2e-5f)) {
+    pn_set_error("network self-test FAILED: MFMA kernels differ from the reference-order kernels by %g at row %d (row %% 32 = %d), "
+                 "output %d — the build's instruction schedule is not the validated one (DESIGN.md 4.3); refusing to run",
+                 (double)worst, wrow, wrow % 32, wcol);
+    return -1;
+  }
+  return 0;
 }
 
 static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16) {

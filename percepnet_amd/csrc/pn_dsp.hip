@@ -275,12 +275,6 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
       }
     }
     PN_WAVE_SYNC();
-    // drain the memory counters and pad the loop back-edge (prophylactic, see pn_dsp_fe.hip)
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef PN_NO_LOOP_PAD
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

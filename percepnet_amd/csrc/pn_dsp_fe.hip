@@ -921,15 +921,6 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
       PN_WAVE_SYNC();
       FE_MARK(18);  // Exp bands + features
     }
-    // Drain every memory counter and pad the loop back-edge.  Prophylactic: a variant of this kernel (batched FFT,
-    // profiles/README.md) produced wrong spectra only for streams handled in the 2nd+ round of the loop, depending on
-    // register allocation, and was correct with this padding; the cause was not pinned down (the toolchain's hazard /
-    // wait-count tracking across loop back-edges is the suspect, cf. pn_mfma_drain).  Costs nothing per 4 streams.
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef PN_NO_LOOP_PAD
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -24,35 +24,6 @@
 
 #define BK 32
 #define LDT 36            // padded LDS row stride (floats)
-// timing experiments only (results become wrong): -DPN_EXP_NOBARRIER, -DPN_EXP_NOSTAGE, -DPN_EXP_NODRAIN
-#if defined(PN_EXP_NOSTAGE) || defined(PN_EXP_NOLOAD)
-#define PN_STAGE_LD(x) do {} while (0)
-#else
-#define PN_STAGE_LD(x) x
-#endif
-#if defined(PN_EXP_NOSTAGE) || defined(PN_EXP_NOSTASH)
-#define PN_STAGE_ST(x) do {} while (0)
-#else
-#define PN_STAGE_ST(x) x
-#endif
-// -DPN_EXP_HOTA / -DPN_EXP_HOTB: every K-tile re-reads K-tile 0 of the activations / weights (cache-hot operands:
-// separates the memory-system cost of the staging loads from their issue cost)
-#ifdef PN_EXP_HOTA
-#define PN_EXP_KA(k) ((k) & 0)
-#else
-#define PN_EXP_KA(k) (k)
-#endif
-#ifdef PN_EXP_HOTB
-#define PN_EXP_KB(k) ((k) & 0)
-#else
-#define PN_EXP_KB(k) (k)
-#endif
-#ifdef PN_EXP_NOBARRIER
-#define PN_SYNC() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PN_SYNC() __syncthreads()
-#endif
-
 // =============================== STRICT kernels ==================================================
 // W in the reference layout [K][ncols] (nnet_data.h); thread = (stream, neuron); the stream index is folded into
 // grid.x (block = nbx * stream + neuron block) because grid.y stops at 65535 and a batch may be larger.
@@ -115,9 +86,6 @@ struct NnShared {
   float A[2][BM][LDT];       // 2 x 18432 B   double-buffered K-tiles
   float B[2][4 * 32][LDT];   // 2 x 18432 B   (up to 4 column tiles: dense NT<=4, GRU 3 gates)
   float tansig[208];
-#ifdef PN_NN_LDS_PAD            // experiment: more than half of the CU's LDS -> at most one GEMM block per CU
-  float pad[PN_NN_LDS_PAD];
-#endif
 };
 
 // ---- software-pipelined staging: global -> registers (issued before the MFMAs of the current
@@ -157,31 +125,6 @@ __device__ __forceinline__ void pn_store_B(float (*Bs)[LDT], const float4 &v) {
   *reinterpret_cast<float4 *>(&Bs[tid >> 3][4 * (tid & 7)]) = v;
 }
 
-template <int NT>
-__device__ __forceinline__ void pn_mma_ktile(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
-                                             int wave, int lane) {
-  const int r = lane & 31, kh = lane >> 5;
-  // keep the caller's prefetch (global loads of the NEXT K-tile) ahead of the MFMAs: without this
-  // hipcc sinks those loads below the MFMA block and their latency is exposed at the LDS write
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float4 a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
-    float4 b[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4 *>(&Bs[32 * t + r][q * 8 + kh * 4]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-  }
-  pn_mfma_drain();
-}
-
 // Register set holding one prefetched K-tile (A: 4 float4, B: up to NB float4 per thread)
 template <int NB> struct PnTileRegs { float4 a[4]; float4 b[NB]; };
 
@@ -201,184 +144,6 @@ __device__ __forceinline__ void pn_tile_stash(float (*As)[LDT], float (*Bs)[LDT]
   for (int t = 0; t < NT; t++) pn_store_B(&Bs[32 * t], R.b[t]);
 }
 
-// Dense / conv-as-dense: out[m][n] = act(bias[n] + sum_k A[m][k] W[k][n]); Wp packed
-// [ctile][ktile][32 cols][32 k-interleaved]; NT column tiles per block.  tps = K-tiles per panel.
-// Pipeline: K-tile g is consumed from LDS buffer g&1 while tile g+1 waits in one register set and
-// the global loads of tile g+2 are issued into the other (two K-tiles of latency budget).
-template <int NT>
-__global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_kernel(
-    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
-    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
-  __shared__ NnShared S;
-  int mt, cb;
-  if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = mt * BM;
-  if (tid < 201) S.tansig[tid] = tansig[tid];
-  floatx16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const int col = (cb * NT + t) * 32 + (lane & 31);
-    const float bv = col < N ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[t][i] = bv;
-  }
-  const float *wbase = Wp + (size_t)(cb * NT) * KT * 1024;
-  PN_PANEL_LOCALS(A);
-  PnTileRegs<NT> R0, R1;
-  pn_dense_fetch<NT>(R0, 0, KT, tps, PN_PANEL_PASS, wbase, m0);
-  pn_dense_fetch<NT>(R1, 1, KT, tps, PN_PANEL_PASS, wbase, m0);
-  pn_tile_stash<NT>(S.A[0], S.B[0], R0);
-  __syncthreads();
-#pragma unroll 1
-  for (int g = 0; g < KT; g += 2) {
-    pn_dense_fetch<NT>(R0, g + 2, KT, tps, PN_PANEL_PASS, wbase, m0);
-    pn_mma_ktile<NT>(S.A[0], S.B[0], acc, wave, lane);
-    pn_tile_stash<NT>(S.A[1], S.B[1], R1);
-    __syncthreads();
-    if (g + 1 < KT) {
-      pn_dense_fetch<NT>(R1, g + 3, KT, tps, PN_PANEL_PASS, wbase, m0);
-      pn_mma_ktile<NT>(S.A[1], S.B[1], acc, wave, lane);
-      pn_tile_stash<NT>(S.A[0], S.B[0], R0);
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const int col = (cb * NT + t) * 32 + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < n_rows && col < N) out[(size_t)row * ldo + col] = pn_act(acc[t][i], act, S.tansig);
-    }
-  }
-}
-
-// Three-accumulator K-tile: acc[I0], acc[I1], acc[I2] += A * B[0..2]
-template <int I0, int I1, int I2>
-__device__ __forceinline__ void pn_mma_ktile3(const float (*As)[LDT], const float (*Bs)[LDT], floatx16 *acc,
-                                              int wave, int lane) {
-  const int r = lane & 31, kh = lane >> 5;
-  __builtin_amdgcn_sched_barrier(0);   // keep the caller's prefetch loads ahead of the MFMAs
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float4 a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
-    const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[r][q * 8 + kh * 4]);
-    const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[32 + r][q * 8 + kh * 4]);
-    const float4 b2 = *reinterpret_cast<const float4 *>(&Bs[64 + r][q * 8 + kh * 4]);
-#define PN_STEP3(c)                                                                       \
-    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b0.c, acc[I0], 0, 0, 0);          \
-    acc[I1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b1.c, acc[I1], 0, 0, 0);          \
-    acc[I2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.c, b2.c, acc[I2], 0, 0, 0);
-    PN_STEP3(x) PN_STEP3(y) PN_STEP3(z) PN_STEP3(w)
-#undef PN_STEP3
-  }
-  pn_mfma_drain();
-}
-
-// Reset-after GRU step for a 128-stream x 32-neuron tile, one software-pipelined sweep over the
-// tile schedule  g = 0 .. KTx+KTh-1 :
-//   [0, KTx)          x tiles   z,r += W_{z,r} x ;  hx += W_h x       3 weight tiles / K-tile
-//   [KTx, KTx+KTh)    h tiles   z,r,tmp += U_{z,r,h} h_old            3 weight tiles / K-tile
-//   epilogue: z,r = sigma(.),  h = (b_h + tmp*r) + hx,  h = tanh(h),  state = z*h_old + (1-z)*h
-// Summation order: z, r and tmp are exactly the reference's chains (bias, then inputs k ascending,
-// then recurrent k ascending; nnet.cpp:135-166).  The candidate's input term W_h x is accumulated
-// as its own k-ascending chain from 0 and added to (b_h + tmp*r) once, where the reference keeps
-// adding the products onto that value one by one (nnet.cpp:166-167): same terms, one different
-// association — it removes a second sweep over x (a third of all K-tiles) and is covered by the
-// same 2e-5 g/r tolerance as the fused-vs-separate rounding (measured: see DESIGN.md).
-// Tile g is consumed from LDS buffer g&1 while tile g+1 waits in a register set and tile g+2 is
-// in flight from L2/HBM; operand addresses are scalar selects of g, so the pipeline runs straight
-// through the phase boundary (KTx and KTh are even).
-// Wp: packed input weights [3N/32 ctiles][KTx][32][32]; Up: packed recurrent [3N/32][N/32][32][32].
-// acc[0..3] = z, r, hx, tmp.
-__global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
-    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
-    float *__restrict__ h_new, int n_rows, int n_mtiles) {
-  __shared__ NnShared S;
-  const int NTn = N >> 5;                       // neuron tiles
-  int mt, nt;
-  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = mt * BM, KTh = N >> 5;
-  const int T1 = KTx, TT = KTx + KTh;
-  const int col = nt * 32 + (lane & 31);
-  if (tid < 201) S.tansig[tid] = tansig[tid];
-
-  floatx16 acc[4];
-  {
-    float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
-    float br = b[N + col]; br += b[4 * N + col];// 147-153
-    const float bt = b[5 * N + col];            // 164
-#pragma unroll
-    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
-  }
-  const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
-              *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
-  const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
-              *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
-  PN_PANEL_LOCALS(X);
-  PnTileRegs<3> R0, R1;
-#define GRU_FETCH(R, gg) do {                                                                              \
-    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
-    const bool p1_ = g_ < T1;                                                                              \
-    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
-    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    pn_load_A((R).a, p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) : h_old, p1_ ? pld : N, PN_EXP_KA(p1_ ? k0_ : kh_ * BK), m0); \
-    (R).b[0] = pn_load_B(p1_ ? Wz + (size_t)PN_EXP_KB(kx_) * 1024 : Uz + (size_t)PN_EXP_KB(kh_) * 1024);   \
-    (R).b[1] = pn_load_B(p1_ ? Wr + (size_t)PN_EXP_KB(kx_) * 1024 : Ur + (size_t)PN_EXP_KB(kh_) * 1024);   \
-    (R).b[2] = pn_load_B(p1_ ? Wh + (size_t)PN_EXP_KB(kx_) * 1024 : Uh + (size_t)PN_EXP_KB(kh_) * 1024);   \
-  } while (0)
-  GRU_FETCH(R0, 0); GRU_FETCH(R1, 1);
-  pn_tile_stash<3>(S.A[0], S.B[0], R0);
-  __syncthreads();
-  // ---- phase 1: z,r,hx += W_{z,r,h} x ---------------------------------------------------------
-#pragma unroll 1
-  for (int g = 0; g < T1; g += 2) {
-    GRU_FETCH(R0, g + 2);
-    pn_mma_ktile3<0, 1, 2>(S.A[0], S.B[0], acc, wave, lane);
-    pn_tile_stash<3>(S.A[1], S.B[1], R1);
-    __syncthreads();
-    GRU_FETCH(R1, g + 3);
-    pn_mma_ktile3<0, 1, 2>(S.A[1], S.B[1], acc, wave, lane);
-    pn_tile_stash<3>(S.A[0], S.B[0], R0);
-    __syncthreads();
-  }
-  // ---- phase 2: z,r,tmp += U_{z,r,h} h_old -------------------------------------------------
-#pragma unroll 1
-  for (int g = T1; g < TT; g += 2) {
-    GRU_FETCH(R0, g + 2);
-    pn_mma_ktile3<0, 1, 3>(S.A[0], S.B[0], acc, wave, lane);
-    pn_tile_stash<3>(S.A[1], S.B[1], R1);
-    __syncthreads();
-    GRU_FETCH(R1, g + 3);
-    pn_mma_ktile3<0, 1, 3>(S.A[1], S.B[1], acc, wave, lane);
-    pn_tile_stash<3>(S.A[0], S.B[0], R0);
-    __syncthreads();
-  }
-  // gates, candidate, blend (nnet.cpp:144,156,161-179)
-  {
-    const float bh = b[2 * N + col];
-    // previous state for the blend: all 16 loads in flight before the activation arithmetic (the state buffers are
-    // allocated with their row count rounded up to the tile, so rows past n_rows are readable; only stores are guarded)
-    float ho[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-      ho[i] = h_old[(size_t)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-#ifdef PN_EXP_NOEPI
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh + ho[i];
-    }
-#else
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
-#endif
-  }
-#undef GRU_FETCH
-}
-
 // =============================== half-tile software pipeline ========================================
 // The K loop above leaves two kinds of bubbles per K-tile in every wave: the two batches of LDS operand
 // reads are waited for right before the MFMAs that use them, and the global prefetch / LDS stash /
@@ -395,27 +160,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_kernel(
 // The order is pinned with sched_barrier(0) between pieces; numerics are unchanged (same MFMAs in the
 // same k order per accumulator).
 template <int NB> struct PnHalfOps { float4 a[2]; float4 b[NB][2]; };
-// timing experiments (results become wrong): drop the LDS operand reads / global prefetch loads / LDS stash of the K loop
-#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NORD)
-#define PN_PIECE_RD(...) do {} while (0);
-#else
-#define PN_PIECE_RD(...) __VA_ARGS__
-#endif
-#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NOLD) || defined(PN_EXP_CLUMP)
-#define PN_PIECE_LD(...) do {} while (0);
-#else
-#define PN_PIECE_LD(...) __VA_ARGS__
-#endif
-#ifdef PN_EXP_CLUMP          // all prefetch loads of an interval back-to-back right after the barrier
-#define PN_CLUMP_LD(...) __VA_ARGS__
-#else
-#define PN_CLUMP_LD(...) do {} while (0);
-#endif
-#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NOST)
-#define PN_PIECE_ST(...) do {} while (0);
-#else
-#define PN_PIECE_ST(...) __VA_ARGS__
-#endif
 #define PN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int NB, int HF, int QQ>
@@ -441,12 +185,7 @@ __device__ __forceinline__ float4 pn_load_A1(const float *__restrict__ p, int ld
 // uniform (SGPR) base + 32-bit per-lane byte offset: hipcc emits `global_load_dwordx4 v, v_off, s[base:base+1]`, no
 // 64-bit VALU address arithmetic in the K loop (the K-tile advance lives in the scalar base)
 __device__ __forceinline__ float4 pn_load_so(const float *__restrict__ ubase, unsigned off_bytes) {
-#ifdef PN_EXP_LD1           // timing experiment: one dword per load instead of four (same instruction count)
-  const float v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + off_bytes);
-  return make_float4(v, v, v, v);
-#else
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ubase) + off_bytes);
-#endif
 }
 __device__ __forceinline__ void pn_store_A1(float (*As)[LDT], const float4 &v, int it) {
   const int idx = threadIdx.x + NN_THREADS * it;
@@ -479,7 +218,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
   const int NTn = N >> 5;
   int mt, nt;
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
-  pn_block_skew();
 #ifdef PN_NN_CLOCKS
   const long long c0_ = __builtin_readcyclecounter(), r0_ = wall_clock64();
 #endif
@@ -519,8 +257,8 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     const bool p1_ = g_ < T1;                                                                              \
     const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + PN_EXP_KA(k0_) : h_old + (size_t)m0 * N + PN_EXP_KA(kh_ * BK)); \
-    const size_t bo_ = (size_t)PN_EXP_KB(p1_ ? kx_ : kh_) * 1024;                                          \
+    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + k0_ : h_old + (size_t)m0 * N + kh_ * BK); \
+    const size_t bo_ = (size_t)p1_ ? kx_ : kh_ * 1024;                                          \
     const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
 #define GP_LA(it) pn_load_so(ap_, p1_ ? aox[it] : aoh[it])
 #define GP_FETCH_ALL(R, gg) do { GP_SEL(gg);                                                               \
@@ -531,50 +269,43 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
 #define GP_INTERVAL(gg, BUF, RF, RS, PI2, CI2, HAVE_PREV) do {                                             \
     GP_SEL((gg) + 2);                                                                                      \
     PN_SB();                                                                                               \
-    PN_CLUMP_LD((RF).a[0] = GP_LA(0); (RF).a[1] = GP_LA(1); (RF).a[2] = GP_LA(2); (RF).a[3] = GP_LA(3);    \
-                (RF).b[0] = pn_load_so(bz_, bo4); (RF).b[1] = pn_load_so(br_, bo4); (RF).b[2] = pn_load_so(bh_, bo4);) PN_SB(); \
-    PN_PIECE_RD(pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
+    pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                        \
     if (HAVE_PREV) PN_G3(op1, 0, x, 0, 1, PI2);                                                            \
-    PN_PIECE_RD(pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
+    pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                        \
     if (HAVE_PREV) PN_G3(op1, 0, y, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).a[0] = GP_LA(0);) PN_SB();                                      \
+    (RF).a[0] = GP_LA(0); PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 0, z, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).a[1] = GP_LA(1);) PN_SB();                                      \
+    (RF).a[1] = GP_LA(1); PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 0, w, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).a[2] = GP_LA(2);) PN_SB();                                      \
+    (RF).a[2] = GP_LA(2); PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 1, x, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).a[3] = GP_LA(3);) PN_SB();                                      \
+    (RF).a[3] = GP_LA(3); PN_SB();                                      \
     if (HAVE_PREV) PN_G3(op1, 1, y, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).b[0] = pn_load_so(bz_, bo4); (RF).b[1] = pn_load_so(br_, bo4);) PN_SB();                             \
+    (RF).b[0] = pn_load_so(bz_, bo4); (RF).b[1] = pn_load_so(br_, bo4); PN_SB();                             \
     if (HAVE_PREV) PN_G3(op1, 1, z, 0, 1, PI2);                                                            \
-    PN_PIECE_LD((RF).b[2] = pn_load_so(bh_, bo4);) PN_SB();                                                         \
+    (RF).b[2] = pn_load_so(bh_, bo4); PN_SB();                                                         \
     if (HAVE_PREV) PN_G3(op1, 1, w, 0, 1, PI2);                                                            \
     PN_G3(op0, 0, x, 0, 1, CI2);                                                                           \
-    PN_PIECE_RD(pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
+    pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                        \
     PN_G3(op0, 0, y, 0, 1, CI2);                                                                           \
-    PN_PIECE_RD(pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane);) PN_SB();                        \
+    pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                        \
     PN_G3(op0, 0, z, 0, 1, CI2);                                                                           \
-    PN_PIECE_ST(pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1);) PN_SB();\
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1); PN_SB();\
     PN_G3(op0, 0, w, 0, 1, CI2);                                                                           \
-    PN_PIECE_ST(pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3);) PN_SB();\
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3); PN_SB();\
     PN_G3(op0, 1, x, 0, 1, CI2);                                                                           \
-    PN_PIECE_ST(pn_store_B(&S.B[(BUF) ^ 1][0], (RS).b[0]); pn_store_B(&S.B[(BUF) ^ 1][32], (RS).b[1]);) PN_SB();\
+    pn_store_B(&S.B[(BUF) ^ 1][0], (RS).b[0]); pn_store_B(&S.B[(BUF) ^ 1][32], (RS).b[1]); PN_SB();\
     PN_G3(op0, 1, y, 0, 1, CI2);                                                                           \
-    PN_PIECE_ST(pn_store_B(&S.B[(BUF) ^ 1][64], (RS).b[2]);) PN_SB();                                         \
+    pn_store_B(&S.B[(BUF) ^ 1][64], (RS).b[2]); PN_SB();                                         \
     PN_G3(op0, 1, z, 0, 1, CI2);                                                                           \
     PN_G3(op0, 1, w, 0, 1, CI2);                                                                           \
-    pn_mfma_drain();                                                                                       \
-    PN_SYNC();                                                                                             \
+    __syncthreads();                                                                                             \
   } while (0)
 
   GP_FETCH_ALL(R0, 0); GP_FETCH_ALL(R1, 1);
   pn_tile_stash<3>(S.A[0], S.B[0], R0);
   __syncthreads();
   // tile g lives in LDS buffer g&1 and, before that, in register set R(g&1)
-#if defined(PN_EXP_PUREMFMA) || defined(PN_EXP_NORD)
-  pn_lds_read_q<3, 0, 0>(op0, S.A[0], S.B[0], wave, lane); pn_lds_read_q<3, 0, 1>(op0, S.A[0], S.B[0], wave, lane);
-  pn_lds_read_q<3, 1, 0>(op1, S.A[0], S.B[0], wave, lane); pn_lds_read_q<3, 1, 1>(op1, S.A[0], S.B[0], wave, lane);
-#endif
   GP_INTERVAL(0, 0, R0, R1, 2, 2, false);
 #pragma unroll 1
   for (int g = 1; g + 1 < T1; g += 2) {
@@ -591,7 +322,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
   GP_INTERVAL(TT - 1, 1, R1, R0, 3, 3, true);
   PN_G3(op1, 0, x, 0, 1, 3); PN_G3(op1, 0, y, 0, 1, 3); PN_G3(op1, 0, z, 0, 1, 3); PN_G3(op1, 0, w, 0, 1, 3);
   PN_G3(op1, 1, x, 0, 1, 3); PN_G3(op1, 1, y, 0, 1, 3); PN_G3(op1, 1, z, 0, 1, 3); PN_G3(op1, 1, w, 0, 1, 3);
-  pn_mfma_drain();
 #undef GP_INTERVAL
 #undef GP_FETCH_ALL
 #undef GP_LA
@@ -612,198 +342,13 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++)
       ho[i] = h_old[(size_t)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-#ifdef PN_EXP_NOEPI
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int row = m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (row < n_rows) h_new[(size_t)row * N + col] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + bh + ho[i];
-    }
-#else
     pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
-#endif
   }
 #ifdef PN_NN_CLOCKS
   if (tid == 0 && N == 512 && blockIdx.x < 8192) {
     unsigned long long *t = pn_nn_trace + (size_t)blockIdx.x * 4;
     t[0] = (unsigned long long)r0_; t[1] = (unsigned long long)wall_clock64();
     t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-  }
-#endif
-}
-
-// =============================== wave-specialised variant ========================================
-// Measured (profiles/README.md, tools/probes/mfma_vmem_probe.hip): a global load costs the wave that issues it
-// about 80 cycles of MFMA issue, while loads issued by ANOTHER wave of the same SIMD are free for it.  Here the
-// block has eight waves: waves 0-3 ("consumers", one 32-row strip each) only read LDS and issue MFMAs; waves
-// 4-7 ("producers") own the whole global -> register -> LDS stream of the block and nothing else.  Same LDS
-// discipline as the kernels above (tile g+1 is written during interval g and read during interval g+1), one
-// block barrier per interval shared by all eight waves, same numerics (same MFMAs, same k order).
-// Consumers read their operands one q-step (8 k values, 12 MFMAs) ahead instead of half a tile ahead: that
-// keeps the kernel at <= 128 registers, i.e. two 8-wave blocks per CU = 4 waves per SIMD, and 8-wave blocks
-// are placed symmetrically on the four SIMDs (a 6-wave variant at 3 waves/SIMD left slots empty for ~40 us
-// at every block turnover: profiles/README.md).
-#define WS_THREADS 512
-template <int NB> struct PnQOps { float4 a; float4 b[NB]; };
-template <int NB, int Q>
-__device__ __forceinline__ void pn_lds_read_1q(PnQOps<NB> &o, const float (*As)[LDT], const float (*Bs)[LDT],
-                                               int wave, int lane) {
-  const int r = lane & 31, kh = lane >> 5;
-  o.a = *reinterpret_cast<const float4 *>(&As[32 * wave + r][Q * 8 + kh * 4]);
-#pragma unroll
-  for (int t = 0; t < NB; t++) o.b[t] = *reinterpret_cast<const float4 *>(&Bs[32 * t + r][Q * 8 + kh * 4]);
-}
-#define PN_Q3(o, c, I0, I1, I2) do {                                                                       \
-    acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[0].c, acc[I0], 0, 0, 0);                 \
-    acc[I1] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[1].c, acc[I1], 0, 0, 0);                 \
-    acc[I2] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a.c, (o).b[2].c, acc[I2], 0, 0, 0);                 \
-    PN_SB(); } while (0)
-#define PN_Q3ALL(o, I0, I1, I2) do { PN_Q3(o, x, I0, I1, I2); PN_Q3(o, y, I0, I1, I2); PN_Q3(o, z, I0, I1, I2); \
-                                     PN_Q3(o, w, I0, I1, I2); } while (0)
-
-// NG consumer groups of four waves (128 rows each) + four producer waves: NG = 1 -> 8 waves, two blocks per CU (4 waves per
-// SIMD, <= 128 registers); NG = 2 -> 12 waves, one block per CU (3 waves per SIMD), the weight tile shared by 256 rows.
-template <int NG> struct NnSharedWs {
-  float A[2][NG * BM][LDT];
-  float B[2][3 * 32][LDT];
-  float tansig[208];
-};
-template <int NG>
-__global__ __launch_bounds__(256 * (NG + 1), (NG == 1 ? 4 : 3)) void pn_gru_mfma_ws_kernel(
-    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
-    float *__restrict__ h_new, int n_rows, int n_mtiles) {
-  __shared__ NnSharedWs<NG> S;
-  const int NTn = N >> 5;
-  int mt, nt;
-  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
-#ifdef PN_NN_CLOCKS
-  const long long r0_ = wall_clock64();
-#endif
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = mt * (NG * BM), KTh = N >> 5;
-  const int T1 = KTx, TT = KTx + KTh;
-  if (tid < 201) S.tansig[tid] = tansig[tid];
-
-  if (wave >= 4 * NG) {
-    // ------------------------------------------------ producers ------------------------------------------
-    const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
-                *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
-    const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
-                *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
-    PN_PANEL_LOCALS(X);
-    const int ptid = tid - 256 * NG;
-    unsigned aox[4 * NG], aoh[4 * NG];
-#pragma unroll
-    for (int it = 0; it < 4 * NG; it++) {
-      const int idx = ptid + NN_THREADS * it;
-      aox[it] = (unsigned)(((idx >> 3) * pld + 4 * (idx & 7)) * 4);
-      aoh[it] = (unsigned)(((idx >> 3) * N + 4 * (idx & 7)) * 4);
-    }
-    const unsigned bo4 = (unsigned)(ptid * 16);
-    struct { float4 a[4 * NG]; float4 b[3]; } R0, R1;
-#define WS_SEL(gg)                                                                                        \
-    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
-    const bool p1_ = g_ < T1;                                                                              \
-    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
-    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + k0_ : h_old + (size_t)m0 * N + kh_ * BK); \
-    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
-    const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
-#define WS_FETCH(R, gg) do { WS_SEL(gg);                                                                   \
-    _Pragma("unroll") for (int it_ = 0; it_ < 4 * NG; it_++) (R).a[it_] = pn_load_so(ap_, p1_ ? aox[it_] : aoh[it_]); \
-    (R).b[0] = pn_load_so(bz_, bo4); (R).b[1] = pn_load_so(br_, bo4); (R).b[2] = pn_load_so(bh_, bo4); } while (0)
-    // the stash helpers index by threadIdx.x & 255 == ptid for the producer half of the block
-#define WS_STASH(R, BUF) do {                                                                              \
-    _Pragma("unroll") for (int it_ = 0; it_ < 4 * NG; it_++) {                                             \
-      const int idx_ = ptid + NN_THREADS * it_; const int row_ = idx_ >> 3, c_ = idx_ & 7;                 \
-      float *dst_ = &S.A[BUF][row_][(c_ >> 1) * 8 + 2 * (c_ & 1)];                                         \
-      *reinterpret_cast<float2 *>(dst_) = make_float2((R).a[it_].x, (R).a[it_].z);                         \
-      *reinterpret_cast<float2 *>(dst_ + 4) = make_float2((R).a[it_].y, (R).a[it_].w); }                   \
-    _Pragma("unroll") for (int t_ = 0; t_ < 3; t_++)                                                       \
-      *reinterpret_cast<float4 *>(&S.B[BUF][32 * t_ + (ptid >> 3)][4 * (ptid & 7)]) = (R).b[t_]; } while (0)
-    WS_FETCH(R0, 0); WS_FETCH(R1, 1);
-    WS_STASH(R0, 0);
-    PN_SYNC();                                   // P_0: tile 0 visible
-    // interval g: fetch tile g+2 into the set tile g just left, stash tile g+1 into the other LDS buffer
-#pragma unroll 1
-    for (int g = 0; g < TT; g += 2) {
-      WS_FETCH(R0, g + 2); PN_SB();
-      WS_STASH(R1, 1);
-      PN_SYNC();
-      WS_FETCH(R1, g + 3); PN_SB();
-      WS_STASH(R0, 0);
-      PN_SYNC();
-    }
-#undef WS_STASH
-#undef WS_FETCH
-#undef WS_SEL
-    return;
-  }
-
-  // -------------------------------------------------- consumers ------------------------------------------
-#ifdef PN_WS_PRIO
-  __builtin_amdgcn_s_setprio(PN_WS_PRIO);        // MFMA issue ahead of the producers' VALU / LDS / VMEM issue on this SIMD
-#endif
-  const int cw = wave & 3, grp = wave >> 2;      // 32-row strip inside a 128-row group
-  const int col = nt * 32 + (lane & 31);
-  floatx16 acc[4];
-  {
-    float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
-    float br = b[N + col]; br += b[4 * N + col];// 147-153
-    const float bt = b[5 * N + col];            // 164
-#pragma unroll
-    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
-  }
-  PnQOps<3> oA, oB;
-  // interval of tile g (LDS buffer BUF): [read q0 | MFMA q3 of tile g-1] [read q1 | MFMA q0] [read q2 | MFMA q1]
-  // [read q3 | MFMA q2] barrier; q3 is consumed at the start of the next interval
-#define WC_INTERVAL(BUF, PI2, CI2, HAVE_PREV) do {                                                         \
-    PN_SB();                                                                                               \
-    pn_lds_read_1q<3, 0>(oA, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
-    if (HAVE_PREV) PN_Q3ALL(oB, 0, 1, PI2);                                                                \
-    pn_lds_read_1q<3, 1>(oB, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
-    PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
-    pn_lds_read_1q<3, 2>(oA, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
-    PN_Q3ALL(oB, 0, 1, CI2);                                                                               \
-    pn_lds_read_1q<3, 3>(oB, &S.A[BUF][BM * grp], S.B[BUF], cw, lane); PN_SB();                                     \
-    PN_Q3ALL(oA, 0, 1, CI2);                                                                               \
-    pn_mfma_drain();                                                                                       \
-    PN_SYNC();                                                                                             \
-  } while (0)
-  PN_SYNC();                                     // P_0
-  WC_INTERVAL(0, 2, 2, false);
-#pragma unroll 1
-  for (int g = 1; g + 1 < T1; g += 2) {
-    WC_INTERVAL(1, 2, 2, true);
-    WC_INTERVAL(0, 2, 2, true);
-  }
-  WC_INTERVAL(1, 2, 2, true);                    // tile T1-1 (T1 even)
-  WC_INTERVAL(0, 2, 3, true);                    // tile T1: first h tile; opens with q3 of the last x tile
-#pragma unroll 1
-  for (int g = T1 + 1; g + 1 < TT; g += 2) {
-    WC_INTERVAL(1, 3, 3, true);
-    WC_INTERVAL(0, 3, 3, true);
-  }
-  WC_INTERVAL(1, 3, 3, true);                    // tile TT-1
-  PN_Q3ALL(oB, 0, 1, 3);
-  pn_mfma_drain();
-#undef WC_INTERVAL
-  {
-    const float bh = b[2 * N + col];
-    // previous state for the blend: all 16 loads in flight before the activation arithmetic (the state buffers are
-    // allocated with their row count rounded up to the tile, so rows past n_rows are readable; only stores are guarded)
-    float ho[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-      ho[i] = h_old[(size_t)(m0 + BM * grp + 32 * cw + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + BM * grp + 32 * cw + 4 * (lane >> 5), n_rows);
-  }
-#ifdef PN_NN_CLOCKS
-  if (tid == 0 && N == 512 && blockIdx.x < 8192) {
-    unsigned long long *t = pn_nn_trace + (size_t)blockIdx.x * 4;
-    t[0] = (unsigned long long)r0_; t[1] = (unsigned long long)wall_clock64();
-    t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    atomicAdd(&pn_nn_clk[0], 1ull); atomicAdd(&pn_nn_clk[1], 1ull); atomicAdd(&pn_nn_clk[2], 1ull);
   }
 #endif
 }
@@ -820,7 +365,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
   __shared__ NnShared S;
   int mt, cb;
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
-  pn_block_skew();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = mt * BM;
   if (tid < 201) S.tansig[tid] = tansig[tid];
@@ -878,8 +422,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
     DP_STOREB(RS, BUF, NT / 2, NT); PN_SB();                                                               \
     PN_DN(op0, 1, z);                                                                                      \
     PN_DN(op0, 1, w);                                                                                      \
-    pn_mfma_drain();                                                                                       \
-    PN_SYNC();                                                                                             \
+    __syncthreads();                                                                                             \
   } while (0)
   pn_dense_fetch<NT>(R0, 0, KT, tps, PN_PANEL_PASS, wbase, m0);
   pn_dense_fetch<NT>(R1, 1, KT, tps, PN_PANEL_PASS, wbase, m0);
@@ -894,7 +437,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
   DP_INTERVAL(KT - 1, 1, R1, R0, true);
   PN_DN(op1, 0, x); PN_DN(op1, 0, y); PN_DN(op1, 0, z); PN_DN(op1, 0, w);
   PN_DN(op1, 1, x); PN_DN(op1, 1, y); PN_DN(op1, 1, z); PN_DN(op1, 1, w);
-  pn_mfma_drain();
 #undef DP_INTERVAL
 #undef DP_STOREB
 #undef DP_LOADB
@@ -909,6 +451,10 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
     }
   }
 }
+
+#ifdef PN_NN_EXPERIMENTS
+#include "experimental/pn_nn_variants.inc"   // first-generation K loop and the wave-specialised variants (not built by default)
+#endif
 
 // ---- host: weight packing ---------------------------------------------------------------------
 // W[K][ncols] (reference layout) -> Wp[CT][ceil(K/32)][32 cols][32 k-interleaved], zero padded,
@@ -950,23 +496,24 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
-#ifndef PN_NN_OLD_PIPE
-  if (KT >= 2 && KT % 2 == 0) {
-    if (NT == 4)
-      hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                         tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-    else
-      hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                         tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-    return;
-  }
-#endif
+#if defined(PN_NN_EXPERIMENTS) && defined(PN_NN_OLD_PIPE)
   if (NT == 4)
     hipLaunchKernelGGL(pn_dense_mfma_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   else
     hipLaunchKernelGGL(pn_dense_mfma_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+#else
+  // the half-tile pipeline consumes K-tiles in pairs: every layer of the PercepNet topology (the only geometry a
+  // context accepts, pn_context.cpp:check_geometry) has an even number of them (4, 20, 48, 80, 4)
+  if (KT < 2 || (KT & 1)) { pn_set_error("pn_launch_dense: %d K-tiles (must be even)", KT); return; }
+  if (NT == 4)
+    hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+  else
+    hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+#endif
 }
 
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
@@ -980,10 +527,10 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-#ifdef PN_NN_OLD_PIPE
+#if defined(PN_NN_EXPERIMENTS) && defined(PN_NN_OLD_PIPE)
   hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
-#elif defined(PN_NN_WS)
+#elif defined(PN_NN_EXPERIMENTS) && defined(PN_NN_WS)
 #if PN_NN_WS == 2
   {
     const int n_mt2 = (n_rows + 2 * BM - 1) / (2 * BM);

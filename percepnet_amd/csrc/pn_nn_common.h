@@ -126,48 +126,12 @@ __device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float
   }
 }
 
-// Toolchain hazard found on ROCm 7.2 / gfx950 (DESIGN.md "MFMA result hazard"): when a loop of
-// v_mfma_f32_32x32x2_f32 exits, hipcc places the first read of the accumulator tuple (a
-// v_accvgpr_mov of element 15, the register the 16th pass writes last) only `s_nop 1` after the
-// final MFMA, and that read returns the value from BEFORE it: output rows 27/31 (mod 32) silently
-// lose the last k-step.  The hazard recogniser does not look across the loop back-edge / exit
-// copies.  Every K-tile therefore ends with an explicit drain of the matrix pipe (32 wait states
-// >= the 19 a 16-pass MFMA needs), pinned in place with scheduling barriers: ~1 % of a K-tile.
-__device__ __forceinline__ void pn_mfma_drain() {
-#ifdef PN_EXP_NODRAIN
-  return;
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// De-phase the two blocks that share a CU.  All blocks of a launch have the same length, so co-resident
-// blocks otherwise stay in lock-step for the whole launch and run their MFMA-free prologue (first tile
-// fetch) and epilogue (activations, state blend) at the same time, leaving the matrix pipe idle.  The
-// dispatcher hands out blocks round-robin over the 8 XCDs and fills every CU once before placing second
-// blocks, so blocks [256, 512) are the second residents of the first generation: delaying them once by
-// PN_BLOCK_SKEW x 8128 cycles keeps the pairs out of phase for all later generations as well.
-#ifndef PN_BLOCK_SKEW
-#define PN_BLOCK_SKEW 0
-#endif
-// Experiment (-DPN_BLOCK_PRIO=n): raise the issue priority of the block that sits in the upper half of the CU's LDS, so
-// that the two co-resident blocks are not arbitrated by age alone.
-__device__ __forceinline__ void pn_block_prio() {
-#ifdef PN_BLOCK_PRIO
-  const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);      // HW_REG_LDS_ALLOC: [7:0] base, [20:12] size
-  if ((la & 0xff) != 0) __builtin_amdgcn_s_setprio(PN_BLOCK_PRIO);
-#endif
-}
-__device__ __forceinline__ void pn_block_skew() {
-  pn_block_prio();
-#if PN_BLOCK_SKEW > 0
-  if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll
-    for (int i = 0; i < PN_BLOCK_SKEW; i++) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-}
+// MFMA result hazard: a VALU / VMEM read of a register written by v_mfma_f32_32x32x2_f32 needs 18 wait
+// states after the MFMA on gfx950 — measured (tools/probes/mfma_waitstate_probe.hip: 17 states still return the old
+// value in every lane, 18 never do) — and that is exactly what hipcc's hazard recogniser inserts, also across a loop
+// exit (tools/probes/mfma_exit_hazard.hip, profiles/r02c_*).  Nothing in these kernels reads an accumulator before the
+// epilogue, so no manual padding is needed; round 1's pn_mfma_drain() (32 wait states per K-tile) is gone.  The
+// margin is zero by construction, which is why pn_ctx_create runs a known-answer self-test of these kernels.
 
 // XCD-aware block numbering: hardware places block b on XCD b % 8; give each XCD whole
 // activation panels (all column tiles of an M tile run on the same XCD's L2).

@@ -105,7 +105,6 @@ __device__ __forceinline__ void h_mma_ktile(const _Float16 (*As)[HLD], const _Fl
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[IDX[t]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[IDX[t]], 0, 0, 0);
   }
-  pn_mfma_drain();
 }
 
 

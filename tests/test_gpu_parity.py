@@ -330,6 +330,19 @@ def test_cli_percepnet_run_matches_reference_cli_contract(blob, oracle, tmp_path
     assert np.array_equal(ao2, ro) and np.array_equal(bo2, rb)      # strict mode: bit-exact, ragged lengths
     r = subprocess.run([exe, "a.pcm"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stderr
+    # multi-device host: --devices shards the pairs over one host thread + one context per listed device (the same
+    # device twice on this 1-GPU box: two threads, two contexts, ragged shards of 3 + 2 streams of different lengths)
+    ins = [synth.synth_stream(20 + i, 9 + 3 * i) for i in range(5)]
+    args = []
+    for i, x in enumerate(ins):
+        (tmp_path / f"i{i}.pcm").write_bytes(x.tobytes()); args += [f"i{i}.pcm", f"o{i}.pcm"]
+    r = subprocess.run([exe, "--model", "m.pnw", "--strict", "--devices", "0,0"] + args, cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, x in enumerate(ins):
+        assert np.array_equal(np.fromfile(tmp_path / f"o{i}.pcm", np.int16), oracle.run_pcm(x)[0]), i
+    r = subprocess.run([exe, "--model", "m.pnw", "--devices", "0,7"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "device 7" in r.stderr and "out of range" in r.stderr       # a bad shard is reported, not hidden
 
 
 def test_multi_frame_device_api(model, oracle):
