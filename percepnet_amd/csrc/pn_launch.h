@@ -29,9 +29,12 @@ void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float 
                        const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
                        float *h_new, void *h_newH, int n_rows);
 int pn_dense_nt(int N);
+// small: 1 = the small-batch kernel family (pn_nn_small.hip), 0 = the batch-GEMM kernels; ignored when strict.
+// pn_small_rows(): the batch size up to which a context picks the small family (PERCEPNET_SMALL_ROWS, default 4096).
+int pn_small_rows();
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
-                     int N, int act, const float *tansig, float *out, int ldo, int n_rows);
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small);
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
-                   float *h_new, int n_rows);
+                   float *h_new, int n_rows, int small);
 

@@ -21,6 +21,7 @@
 // STRICT path (PN_NN_STRICT): one lane per (stream, neuron), separate v_mul/v_add in the
 // reference's order (file compiled with -ffp-contract=off) — bit-identical to the CPU reference.
 #include "pn_nn_common.h"
+#include <stdlib.h>
 
 #define BK 32
 #define LDT 36            // padded LDS row stride (floats)
@@ -484,11 +485,26 @@ void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round
 int pn_dense_nt(int N) { return (N % 128 == 0) ? 4 : 2; }
 
 // ---- launchers -----------------------------------------------------------------------------------
+// Batches of at most this many streams run the small-batch kernel family (pn_nn_small.hip: one 32x32 tile and one
+// accumulator chain per wave, 3-4x more blocks), larger ones the batch-GEMM kernels above.  Same numerics either way.
+// PERCEPNET_SMALL_ROWS overrides the crossover (0 = never use the small kernels).
+int pn_small_rows() {                     // read at every context creation (tests switch families through it)
+  const char *e = getenv("PERCEPNET_SMALL_ROWS");
+  return e ? atoi(e) : 4096;
+}
+void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
+                           const float *tansig, float *out, int ldo, int n_rows, int ct_padded);
+void pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
+                         const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
-                     int N, int act, const float *tansig, float *out, int ldo, int n_rows) {
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small) {
   if (strict) {
     const int nbx = (N + 63) / 64;
     hipLaunchKernelGGL(pn_dense_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo, nbx);
+    return;
+  }
+  if (small) {
+    pn_launch_dense_small(st, A, Wp, bias, N, act, tansig, out, ldo, n_rows, pn_ct_padded(N, pn_dense_nt(N)));
     return;
   }
   const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
@@ -518,10 +534,14 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
 
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
-                   float *h_new, int n_rows) {
+                   float *h_new, int n_rows, int small) {
   if (strict) {
     const int nbx = (N + 63) / 64;
     hipLaunchKernelGGL(pn_gru_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, X, h_old, W, U, b, N, act, tansig, h_new, nbx);
+    return;
+  }
+  if (small) {
+    pn_launch_gru_small(st, X, h_old, Wp, Up, b, N, act, tansig, h_new, n_rows);
     return;
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels

@@ -1,0 +1,206 @@
+// Small-batch network kernels: the latency regime of BASELINE configs[1] (about a thousand concurrent streams).
+//
+// The batch-GEMM kernels of pn_nn.hip give every wave a 32-row x 96/128-column tile and walk the whole K range with
+// it: 16-49 K-tiles of 48-64 dependent-pipe MFMAs, i.e. 43-85 us of matrix-pipe time per block however few blocks
+// there are.  At 1024 streams that is 8 M tiles: a 512->512 GRU step runs on 128 of the 256 CUs, one wave per SIMD,
+// for 61 us, and the ten layers of compute_rnn (reference rnn.cpp:42-81) take 0.62 ms of a 0.86 ms frame.
+//
+// Here a wave owns ONE 32x32 output tile and one accumulator chain, and a block is the set of waves that share an
+// activation tile:
+//   * dense / conv-as-dense: 32 rows x 4 column tiles per block (4 waves); K-tile = 16 MFMAs per wave;
+//   * GRU: 32 rows x 32 neurons per block, one wave per GATE (z | r | candidate): the z and r waves walk the x tiles
+//     then the h tiles, the candidate wave accumulates W_h x during the x tiles and b_rh + U_h h during the h tiles
+//     (the same three chains, in the same k order, as pn_gru_mfma_p_kernel and nnet.cpp:135-167); the three
+//     accumulators meet in LDS for the gating epilogue.
+// A 512->512 GRU step at 1024 streams becomes 512 blocks x 3 waves with 1/3 of the per-wave chain.  The activation
+// tile (shared by the block's waves) is staged through LDS as in the batch kernels; the weight tile of a wave is its
+// own, pre-packed in MFMA fragment order (pn_pack_weights), so it goes global -> registers directly, one K-tile ahead.
+// Numerics are identical to the batch kernels (same MFMA, same chains): results do not depend on which family ran.
+#include "pn_nn_common.h"
+
+#define SBM 32            // rows (streams) per block
+#define SLDT 36           // padded LDS row stride (floats): conflict-free ds_read_b128, as in pn_nn.hip
+
+struct SmShared {
+  float A[2][SBM][SLDT];  // double-buffered activation K-tile, k-interleaved rows (k = 8q + 2s + kh at q*8 + kh*4 + s)
+  float E[4][SBM][33];    // GRU: z | r | W_h x | b_rh + U_h h  accumulators of the block's three waves
+  float tansig[208];
+};
+
+// activation K-tile: 32 rows x 32 k = 256 float4, loaded by the first 256 threads of the block
+template <int NTHREADS>
+__device__ __forceinline__ void sm_load_A(float4 (&ra)[(256 + NTHREADS - 1) / NTHREADS], const float *__restrict__ p,
+                                          int ld, int k0, int m0) {
+#pragma unroll
+  for (int it = 0; it < (256 + NTHREADS - 1) / NTHREADS; it++) {
+    const int idx = threadIdx.x + NTHREADS * it;
+    if (idx < 256) ra[it] = *reinterpret_cast<const float4 *>(p + (size_t)(m0 + (idx >> 3)) * ld + k0 + 4 * (idx & 7));
+  }
+}
+template <int NTHREADS>
+__device__ __forceinline__ void sm_store_A(float (*As)[SLDT], const float4 (&ra)[(256 + NTHREADS - 1) / NTHREADS]) {
+#pragma unroll
+  for (int it = 0; it < (256 + NTHREADS - 1) / NTHREADS; it++) {
+    const int idx = threadIdx.x + NTHREADS * it;
+    if (idx < 256) {
+      const int row = idx >> 3, c = idx & 7;
+      float *dst = &As[row][(c >> 1) * 8 + 2 * (c & 1)];
+      *reinterpret_cast<float2 *>(dst) = make_float2(ra[it].x, ra[it].z);
+      *reinterpret_cast<float2 *>(dst + 4) = make_float2(ra[it].y, ra[it].w);
+    }
+  }
+}
+// this wave's packed 32(col) x 32(k) weight tile, in fragment order: lane (col r, k-half kh) takes its four float4
+__device__ __forceinline__ void sm_load_B(float4 (&rb)[4], const float *__restrict__ tile, int lane) {
+  const float *p = tile + (lane & 31) * 32 + (lane >> 5) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; q++) rb[q] = *reinterpret_cast<const float4 *>(p + q * 8);
+}
+__device__ __forceinline__ void sm_mma_tile(floatx16 &acc, const float (*As)[SLDT], const float4 (&rb)[4], int lane) {
+  const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float4 a = *reinterpret_cast<const float4 *>(&As[r][q * 8 + kh * 4]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, rb[q].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, rb[q].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, rb[q].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, rb[q].w, acc, 0, 0, 0);
+  }
+}
+
+// Dense / conv-as-dense (compute_dense, compute_conv1d: nnet.cpp:105-118,182-200): out = act(bias + A W), A = up to five
+// row-major panels side by side (PnSegs), Wp packed [CT][KT][32][32] with CT padded to a multiple of the batch kernels'
+// NT (pn_pack_weights).  Block = 32 rows x 4 column tiles; wave w owns column tile 4*cb + w (idle beyond ct_total).
+__global__ __launch_bounds__(256) void pn_dense_small_kernel(
+    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_cblocks, int ct_total) {
+  __shared__ SmShared S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = blockIdx.x / n_cblocks, cb = blockIdx.x - mt * n_cblocks;
+  const int m0 = mt * SBM, ct = cb * 4 + wave;
+  const bool live = ct < ct_total;
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+  const int col = ct * 32 + (lane & 31);
+  floatx16 acc;
+  {
+    const float bv = (live && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = bv;
+  }
+  const float *wt = Wp + (size_t)(live ? ct : 0) * KT * 1024;
+  PN_PANEL_LOCALS(A);
+  float4 ra[1], rb[4], nb[4];
+  sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, 0), pld, 0, m0);
+  sm_load_B(rb, wt, lane);
+  sm_store_A<256>(S.A[0], ra);
+  if (KT > 1) sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, 1 / tps), pld, (1 % tps) * 32, m0);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < KT; g++) {
+    if (g + 1 < KT) sm_load_B(nb, wt + (size_t)(g + 1) * 1024, lane);
+    if (live) sm_mma_tile(acc, S.A[g & 1], rb, lane);
+    if (g + 1 < KT) sm_store_A<256>(S.A[(g + 1) & 1], ra);
+    if (g + 2 < KT) { const int sg = (g + 2) / tps; sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, sg), pld, (g + 2 - sg * tps) * 32, m0); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) rb[q] = nb[q];
+  }
+  if (live && col < N) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (row < n_rows) out[(size_t)row * ldo + col] = pn_act(acc[i], act, S.tansig);
+    }
+  }
+}
+
+// Reset-after GRU step (compute_gru, nnet.cpp:120-180) for 32 streams x 32 neurons; wave = gate.
+__global__ __launch_bounds__(192) void pn_gru_small_kernel(
+    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
+    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
+    float *__restrict__ h_new, int n_rows) {
+  __shared__ SmShared S;
+  const int tid = threadIdx.x, lane = tid & 63, gate = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NTn = N >> 5, KTh = N >> 5;
+  const int mt = blockIdx.x / NTn, nt = blockIdx.x - mt * NTn;
+  const int m0 = mt * SBM, T1 = KTx, TT = KTx + KTh;
+  const int col = nt * 32 + (lane & 31);
+  if (tid < 201) S.tansig[tid] = tansig[tid];
+  floatx16 acc, acc2;                       // acc: z | r | W_h x ;  acc2 (candidate wave only): b_rh + U_h h
+  {
+    float b0;
+    if (gate == 0) { b0 = b[col]; b0 += b[3 * N + col]; }             // nnet.cpp:135-141
+    else if (gate == 1) { b0 = b[N + col]; b0 += b[4 * N + col]; }    // 147-153
+    else b0 = 0.f;
+    const float bt = b[5 * N + col];                                  // 164
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[i] = b0; acc2[i] = bt; }
+  }
+  const float *wx = Wp + (size_t)(gate * NTn + nt) * KTx * 1024, *wh = Up + (size_t)(gate * NTn + nt) * KTh * 1024;
+  PN_PANEL_LOCALS(X);
+  // tile g: x tiles [0, T1) then h tiles [T1, TT)
+#define SG_A(g_) ((g_) < T1 ? pn_seg_ptr(PN_PANEL_PASS, (g_) / tps) : h_old)
+#define SG_LD(g_) ((g_) < T1 ? pld : N)
+#define SG_K0(g_) (((g_) < T1 ? (g_) % tps : (g_) - T1) * 32)
+#define SG_B(g_) ((g_) < T1 ? wx + (size_t)(g_) * 1024 : wh + (size_t)((g_) - T1) * 1024)
+  float4 ra[2], rb[4], nb[4];
+  sm_load_A<192>(ra, SG_A(0), SG_LD(0), SG_K0(0), m0);
+  sm_load_B(rb, SG_B(0), lane);
+  sm_store_A<192>(S.A[0], ra);
+  sm_load_A<192>(ra, SG_A(1), SG_LD(1), SG_K0(1), m0);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < TT; g++) {
+    if (g + 1 < TT) sm_load_B(nb, SG_B(g + 1), lane);
+    if (gate == 2 && g >= T1) sm_mma_tile(acc2, S.A[g & 1], rb, lane);
+    else sm_mma_tile(acc, S.A[g & 1], rb, lane);
+    if (g + 1 < TT) sm_store_A<192>(S.A[(g + 1) & 1], ra);
+    if (g + 2 < TT) sm_load_A<192>(ra, SG_A(g + 2), SG_LD(g + 2), SG_K0(g + 2), m0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) rb[q] = nb[q];
+  }
+#undef SG_A
+#undef SG_LD
+#undef SG_K0
+#undef SG_B
+  // the three waves' accumulators meet in LDS: E[0] z, E[1] r, E[2] W_h x, E[3] b_rh + U_h h
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+    S.E[gate][row][lane & 31] = acc[i];
+    if (gate == 2) S.E[3][row][lane & 31] = acc2[i];
+  }
+  __syncthreads();
+  // gates, candidate, blend (nnet.cpp:144,156,161-179), one output per thread and pass; same arithmetic as pn_gru_epilogue
+  for (int e = tid; e < SBM * 32; e += 192) {
+    const int row = e >> 5, c = e & 31, grow = m0 + row, gcol = nt * 32 + c;
+    const float z = pn_sigmoid(S.E[0][row][c], S.tansig);
+    const float r = pn_sigmoid(S.E[1][row][c], S.tansig);
+    float h = b[2 * N + gcol];
+    h += S.E[3][row][c] * r;
+    float hp = h + S.E[2][row][c];
+    hp = pn_act(hp, act, S.tansig);
+    if (grow < n_rows) {
+      const float ho = h_old[(size_t)grow * N + gcol];
+      h_new[(size_t)grow * N + gcol] = z * ho + (1 - z) * hp;
+    }
+  }
+}
+
+// ---- launchers (called from pn_launch_dense / pn_launch_gru when the batch is small) -------------------------------
+void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
+                           const float *tansig, float *out, int ldo, int n_rows, int ct_padded) {
+  const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
+  const int n_mt = (n_rows + SBM - 1) / SBM, ct_total = (N + 31) / 32, n_cblocks = (ct_total + 3) / 4;
+  (void)ct_padded;
+  hipLaunchKernelGGL(pn_dense_small_kernel, dim3(n_mt * n_cblocks), dim3(256), 0, st, A, Wp, bias, N, KT, tps, act, tansig,
+                     out, ldo, n_rows, n_cblocks, ct_total);
+}
+void pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
+                         const float *b, int N, int act, const float *tansig, float *h_new, int n_rows) {
+  const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;
+  const int n_mt = (n_rows + SBM - 1) / SBM;
+  hipLaunchKernelGGL(pn_gru_small_kernel, dim3(n_mt * (N / 32)), dim3(192), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+                     tansig, h_new, n_rows);
+}

@@ -574,3 +574,27 @@ def test_relinked_reference_cli(blob, oracle, tmp_path):
     r = subprocess.run([build.RELINKED, "a.pcm", "as.pcm"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
                        env=dict(env, PERCEPNET_STRICT="1"))
     assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "as.pcm", np.int16), ro)      # bit-exact in STRICT
+
+
+def test_small_batch_and_batch_gemm_kernel_families_agree_bit_for_bit(model, oracle):
+    """Contexts of up to PERCEPNET_SMALL_ROWS streams (default 4096) run the small-batch network kernels (pn_nn_small.hip:
+    one 32x32 tile and one accumulator chain per wave, a GRU's three gates on three waves), larger ones the batch-GEMM
+    kernels.  Both evaluate the same k-ordered fmaf chains, so the SAME batch through either family must give bit-identical
+    g/r and PCM — and both must sit within the MFMA tolerance of the oracle.  Ragged size: 2 M tiles of the batch family,
+    10 of the small one, the last ragged in both."""
+    B, T = 300, 12
+    pcm = synth.synth_batch(B, T, first_stream=40)
+    res = {}
+    for fam, rows in (("small", "4096"), ("batch", "0")):
+        os.environ["PERCEPNET_SMALL_ROWS"] = rows
+        try:
+            ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+        finally:
+            del os.environ["PERCEPNET_SMALL_ROWS"]
+        res[fam] = ctx.run_pcm(pcm)
+        ctx.close()
+    assert np.array_equal(res["small"][0], res["batch"][0])
+    assert np.array_equal(res["small"][1].view(np.uint32), res["batch"][1].view(np.uint32))
+    ro, rg, _, _ = oracle.run_batch(pcm, want_feat=False)
+    assert np.abs(res["small"][0].astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+    assert np.abs(res["small"][1] - rg).max() <= GR_TOL
