@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
     const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
     const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + k0_ : h_old + (size_t)m0 * N + kh_ * BK); \
-    const size_t bo_ = (size_t)p1_ ? kx_ : kh_ * 1024;                                          \
+    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                         \
     const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
 #define GP_LA(it) pn_load_so(ap_, p1_ ? aox[it] : aoh[it])
 #define GP_FETCH_ALL(R, gg) do { GP_SEL(gg);                                                               \

@@ -89,22 +89,33 @@ __global__ __launch_bounds__(256) void pn_dense_small_kernel(
   }
   const float *wt = Wp + (size_t)(live ? ct : 0) * KT * 1024;
   PN_PANEL_LOCALS(A);
-  float4 ra[1], rb[4], nb[4];
+  // Two weight-tile register sets (rbA: even K-tiles, rbB: odd ones), no copies: the loads of tile g+1 are issued
+  // before the MFMAs of tile g and first waited for a whole K-tile later.  The order is pinned with sched_barrier
+  // (hipcc otherwise sinks the prefetch below the MFMA block and its latency is exposed every step).  KT is even.
+  // Prefetches are UNCONDITIONAL (past-the-end ones re-read the last tile, unused): behind a branch the waitcnt pass
+  // must assume the loads may not have been issued and waits vmcnt(3..0) right after them — measured 3.5x slower.
+  float4 ra[1], rbA[4], rbB[4];
+#define SD_STEP(g_, RB_CUR, RB_NEXT) do {                                                                  \
+    sm_load_B(RB_NEXT, wt + (size_t)((g_) + 1 < KT ? (g_) + 1 : KT - 1) * 1024, lane);                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (live) sm_mma_tile(acc, S.A[(g_) & 1], RB_CUR, lane);                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if ((g_) + 1 < KT) sm_store_A<256>(S.A[((g_) + 1) & 1], ra);                                           \
+    { const int g2 = (g_) + 2 < KT ? (g_) + 2 : KT - 1, sg = g2 / tps;                                     \
+      sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, sg), pld, (g2 - sg * tps) * 32, m0); }                  \
+    __syncthreads();                                                                                       \
+  } while (0)
   sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, 0), pld, 0, m0);
-  sm_load_B(rb, wt, lane);
+  sm_load_B(rbA, wt, lane);
   sm_store_A<256>(S.A[0], ra);
-  if (KT > 1) sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, 1 / tps), pld, (1 % tps) * 32, m0);
+  sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, 1 / tps), pld, (1 % tps) * 32, m0);
   __syncthreads();
 #pragma unroll 1
-  for (int g = 0; g < KT; g++) {
-    if (g + 1 < KT) sm_load_B(nb, wt + (size_t)(g + 1) * 1024, lane);
-    if (live) sm_mma_tile(acc, S.A[g & 1], rb, lane);
-    if (g + 1 < KT) sm_store_A<256>(S.A[(g + 1) & 1], ra);
-    if (g + 2 < KT) { const int sg = (g + 2) / tps; sm_load_A<256>(ra, pn_seg_ptr(PN_PANEL_PASS, sg), pld, (g + 2 - sg * tps) * 32, m0); }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) rb[q] = nb[q];
+  for (int g = 0; g < KT; g += 2) {
+    SD_STEP(g, rbA, rbB);
+    SD_STEP(g + 1, rbB, rbA);
   }
+#undef SD_STEP
   if (live && col < N) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -143,23 +154,28 @@ __global__ __launch_bounds__(192) void pn_gru_small_kernel(
 #define SG_LD(g_) ((g_) < T1 ? pld : N)
 #define SG_K0(g_) (((g_) < T1 ? (g_) % tps : (g_) - T1) * 32)
 #define SG_B(g_) ((g_) < T1 ? wx + (size_t)(g_) * 1024 : wh + (size_t)((g_) - T1) * 1024)
-  float4 ra[2], rb[4], nb[4];
+  float4 ra[2], rbA[4], rbB[4];            // weight-tile register sets for even / odd tiles (see pn_dense_small_kernel)
+#define SG_STEP(g_, RB_CUR, RB_NEXT) do {                                                                  \
+    { const int g1 = (g_) + 1 < TT ? (g_) + 1 : TT - 1; sm_load_B(RB_NEXT, SG_B(g1), lane); }               \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (gate == 2 && (g_) >= T1) sm_mma_tile(acc2, S.A[(g_) & 1], RB_CUR, lane);                           \
+    else sm_mma_tile(acc, S.A[(g_) & 1], RB_CUR, lane);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if ((g_) + 1 < TT) sm_store_A<192>(S.A[((g_) + 1) & 1], ra);                                           \
+    { const int g2 = (g_) + 2 < TT ? (g_) + 2 : TT - 1; sm_load_A<192>(ra, SG_A(g2), SG_LD(g2), SG_K0(g2), m0); } \
+    __syncthreads();                                                                                       \
+  } while (0)
   sm_load_A<192>(ra, SG_A(0), SG_LD(0), SG_K0(0), m0);
-  sm_load_B(rb, SG_B(0), lane);
+  sm_load_B(rbA, SG_B(0), lane);
   sm_store_A<192>(S.A[0], ra);
   sm_load_A<192>(ra, SG_A(1), SG_LD(1), SG_K0(1), m0);
   __syncthreads();
 #pragma unroll 1
-  for (int g = 0; g < TT; g++) {
-    if (g + 1 < TT) sm_load_B(nb, SG_B(g + 1), lane);
-    if (gate == 2 && g >= T1) sm_mma_tile(acc2, S.A[g & 1], rb, lane);
-    else sm_mma_tile(acc, S.A[g & 1], rb, lane);
-    if (g + 1 < TT) sm_store_A<192>(S.A[(g + 1) & 1], ra);
-    if (g + 2 < TT) sm_load_A<192>(ra, SG_A(g + 2), SG_LD(g + 2), SG_K0(g + 2), m0);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) rb[q] = nb[q];
+  for (int g = 0; g < TT; g += 2) {          // TT = KTx + KTh is even for every GRU of the topology (32, 36)
+    SG_STEP(g, rbA, rbB);
+    SG_STEP(g + 1, rbB, rbA);
   }
+#undef SG_STEP
 #undef SG_A
 #undef SG_LD
 #undef SG_K0
