@@ -127,7 +127,8 @@ struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
 
 struct pn_ctx {
   int device, B, nn_mode;
-  int small;                       // network kernel family: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
+  int small, small_gru;            // network kernel family per layer kind: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
+  int fe_g2;                       // front end: 1 = two streams per wavefront (pn_dsp_fe_g2.hip), small batches only
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
   int64_t t;                       // frames done: indexes the DSP rings (hist slot t%12, yring/eyring t%6)
@@ -240,7 +241,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   DeviceGuard _dg(device);
   if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = n_streams <= pn_small_rows(); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = n_streams <= pn_small_rows(); c->small_gru = n_streams <= pn_small_gru_rows(); c->fe_g2 = c->small && !(getenv("PERCEPNET_FE_G2") && !atoi(getenv("PERCEPNET_FE_G2"))); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -430,7 +431,7 @@ static void launch_rnn(pn_ctx *c) {
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
     if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
-    else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small);
+    else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
     x = hn;
   }
   const float *g1 = c->gru[0] + (size_t)nxt * Bp * 512, *g2 = c->gru[1] + (size_t)nxt * Bp * 512,
@@ -441,7 +442,7 @@ static void launch_rnn(pn_ctx *c) {
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
     if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
-    else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }
+    else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
@@ -521,8 +522,8 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
   PN_ON_DEVICE(c);
   { Scope sc(c, KF_FRONTEND);
-    pn_launch_frontend(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring,
-                       c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr); }
+    (c->fe_g2 ? pn_launch_frontend_g2 : pn_launch_frontend)(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f,
+        c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr); }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
     // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6

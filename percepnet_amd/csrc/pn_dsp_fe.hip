@@ -839,24 +839,30 @@ __global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
         // each lane filters 4 consecutive samples per step: one (unaligned) dwordx4 load per tap instead of four
         // dword loads — the phase is bound by the number of VMEM instructions a wave can issue, not by bytes
 #ifndef PN_FE_COMB_CH
-#define PN_FE_COMB_CH 5
+#define PN_FE_COMB_CH (L == 16 ? 5 : 4)
 #endif
         constexpr int CH = PN_FE_COMB_CH;               // 4-sample groups per lane per chunk: 7*CH dwordx4 loads in flight
-        constexpr int NG = PN_WINDOW / 4 / L;           // groups per lane (15 at L=16)
+        constexpr int NGT = PN_WINDOW / 4;              // 240 groups of 4 samples
+        constexpr int NG = (NGT + L - 1) / L;           // groups per lane (15 at L=16; 8 at L=32, the last one half empty)
+        constexpr bool RAGGED = NGT % L != 0;
         static_assert(NG % CH == 0, "chunk");
 #pragma unroll 1
         for (int q0 = 0; q0 < NG; q0 += CH) {
           fe_f4u cv[CH][7];
 #pragma unroll
-          for (int q = 0; q < CH; q++)
+          for (int q = 0; q < CH; q++) {
+            const int gi = l + L * (q0 + q), gc = (RAGGED && gi >= NGT) ? 0 : gi;
 #pragma unroll
             for (int k = -PN_COMB_M; k <= PN_COMB_M; k++)
-              cv[q][k + PN_COMB_M] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(2400 - pitch_index * k + 4 * (l + L * (q0 + q)), base_slot));
+              cv[q][k + PN_COMB_M] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(2400 - pitch_index * k + 4 * gc, base_slot));
+          }
 #pragma unroll
           for (int q = 0; q < CH; q++) {
+            const int gi = l + L * (q0 + q);
+            if (RAGGED && gi >= NGT) continue;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-              const int i = 4 * (l + L * (q0 + q)) + c;
+              const int i = 4 * gi + c;
               float p = 0;
 #pragma unroll
               for (int k = 0; k < 7; k++) p += cv[q][k][c] * S.comb_w[k];

@@ -9,6 +9,11 @@ struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
                         int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
                         float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+// the same kernel instantiated with two streams per wavefront (pn_dsp_fe_g2.hip): lower latency per stream, lower
+// throughput — used by small-batch contexts
+void pn_launch_frontend_g2(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
+                           int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
+                           float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,
@@ -32,6 +37,7 @@ int pn_dense_nt(int N);
 // small: 1 = the small-batch kernel family (pn_nn_small.hip), 0 = the batch-GEMM kernels; ignored when strict.
 // pn_small_rows(): the batch size up to which a context picks the small family (PERCEPNET_SMALL_ROWS, default 4096).
 int pn_small_rows();
+int pn_small_gru_rows();
 void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small);
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,

@@ -122,8 +122,10 @@ __device__ __forceinline__ float4 pn_load_B(const float *__restrict__ tile) {
   return *reinterpret_cast<const float4 *>(tile + (tid >> 3) * 32 + 4 * (tid & 7));
 }
 __device__ __forceinline__ void pn_store_B(float (*Bs)[LDT], const float4 &v) {
+  // float4 #tid of a packed tile = chunk (q, kh) = tid >> 5 of column tid & 31 (pn_pack_weights) -> row-major padded LDS
+  // image Bs[col][q*8 + kh*4 ..]; 8 consecutive lanes hit rows 36 floats apart = 8 distinct bank quads: conflict-free
   const int tid = threadIdx.x;
-  *reinterpret_cast<float4 *>(&Bs[tid >> 3][4 * (tid & 7)]) = v;
+  *reinterpret_cast<float4 *>(&Bs[tid & 31][4 * (tid >> 5)]) = v;
 }
 
 // Register set holding one prefetched K-tile (A: 4 float4, B: up to NB float4 per thread)
@@ -458,9 +460,13 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
 #endif
 
 // ---- host: weight packing ---------------------------------------------------------------------
-// W[K][ncols] (reference layout) -> Wp[CT][ceil(K/32)][32 cols][32 k-interleaved], zero padded,
+// W[K][ncols] (reference layout) -> Wp[CT][ceil(K/32)][tile of 1024 floats], zero padded,
 // CT = ceil(ncols/32) rounded up to a multiple of ct_round (the kernel's column tiles per block).
-// position of k_local = 8q + 2s + kh inside a tile row is q*8 + kh*4 + s.
+// A tile is stored in MFMA FRAGMENT order: element (column j, k_local = 8q + 2s + kh) at ((q*2 + kh)*32 + j)*4 + s, i.e.
+// eight 512-byte chunks (q, kh), each holding for the 32 columns the four k values one lane feeds to four consecutive
+// MFMA k-steps.  A wavefront whose lane = kh*32 + j reads chunk pair q with ONE fully coalesced 1 KB load (the
+// small-batch kernels take their B operand straight from global memory like that); the batch kernels stage a tile into
+// LDS with 256 linear float4 loads and un-permute while storing (pn_store_B).
 static inline int pn_ct_padded(int ncols, int ct_round) {
   const int CT = (ncols + 31) / 32;
   return ((CT + ct_round - 1) / ct_round) * ct_round;
@@ -478,7 +484,7 @@ void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round
         for (int kl = 0; kl < 32; kl++) {
           const int q = kl >> 3, s = (kl & 7) >> 1, kh = kl & 1;
           const int k = kt * 32 + kl, c = ct * 32 + j;
-          tile[j * 32 + q * 8 + kh * 4 + s] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
+          tile[((q * 2 + kh) * 32 + j) * 4 + s] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
         }
     }
 }
@@ -487,10 +493,17 @@ int pn_dense_nt(int N) { return (N % 128 == 0) ? 4 : 2; }
 // ---- launchers -----------------------------------------------------------------------------------
 // Batches of at most this many streams run the small-batch kernel family (pn_nn_small.hip: one 32x32 tile and one
 // accumulator chain per wave, 3-4x more blocks), larger ones the batch-GEMM kernels above.  Same numerics either way.
-// PERCEPNET_SMALL_ROWS overrides the crossover (0 = never use the small kernels).
+// Measured crossovers (profiles/r02e_small_batch_study.txt): the dense/conv kernels win up to 4096 streams, the
+// gate-per-wave GRU up to ~1500.  PERCEPNET_SMALL_ROWS / PERCEPNET_SMALL_GRU_ROWS override them (0 = never).
 int pn_small_rows() {                     // read at every context creation (tests switch families through it)
   const char *e = getenv("PERCEPNET_SMALL_ROWS");
   return e ? atoi(e) : 4096;
+}
+int pn_small_gru_rows() {
+  const char *e = getenv("PERCEPNET_SMALL_GRU_ROWS");
+  if (e) return atoi(e);
+  const int d = pn_small_rows();
+  return d < 1536 ? d : 1536;
 }
 void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
                            const float *tansig, float *out, int ldo, int n_rows, int ct_padded);

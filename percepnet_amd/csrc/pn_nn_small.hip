@@ -50,11 +50,12 @@ __device__ __forceinline__ void sm_store_A(float (*As)[SLDT], const float4 (&ra)
     }
   }
 }
-// this wave's packed 32(col) x 32(k) weight tile, in fragment order: lane (col r, k-half kh) takes its four float4
+// this wave's packed 32(col) x 32(k) weight tile, stored in fragment order (pn_pack_weights): lane (col r, k-half kh)
+// takes float4 number q*64 + lane for q = 0..3 — four fully coalesced 1 KB loads
 __device__ __forceinline__ void sm_load_B(float4 (&rb)[4], const float *__restrict__ tile, int lane) {
-  const float *p = tile + (lane & 31) * 32 + (lane >> 5) * 4;
+  const float *p = tile + lane * 4;
 #pragma unroll
-  for (int q = 0; q < 4; q++) rb[q] = *reinterpret_cast<const float4 *>(p + q * 8);
+  for (int q = 0; q < 4; q++) rb[q] = *reinterpret_cast<const float4 *>(p + q * 256);
 }
 __device__ __forceinline__ void sm_mma_tile(floatx16 &acc, const float (*As)[SLDT], const float4 (&rb)[4], int lane) {
   const int r = lane & 31, kh = lane >> 5;
