@@ -493,7 +493,7 @@ int pn_dense_nt(int N) { return (N % 128 == 0) ? 4 : 2; }
 // ---- launchers -----------------------------------------------------------------------------------
 // Batches of at most this many streams run the small-batch kernel family (pn_nn_small.hip: one 32x32 tile and one
 // accumulator chain per wave, 3-4x more blocks), larger ones the batch-GEMM kernels above.  Same numerics either way.
-// Measured crossovers (profiles/r02e_small_batch_study.txt): the dense/conv kernels win up to 4096 streams, the
+// Measured crossovers (profiles/r02f_small_batch_study.txt): the dense/conv kernels win up to 4096 streams, the
 // gate-per-wave GRU up to ~1500.  PERCEPNET_SMALL_ROWS / PERCEPNET_SMALL_GRU_ROWS override them (0 = never).
 int pn_small_rows() {                     // read at every context creation (tests switch families through it)
   const char *e = getenv("PERCEPNET_SMALL_ROWS");
