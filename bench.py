@@ -342,8 +342,10 @@ def main():
                 traffic, traffic_src = pmc_traffic_bytes(B)
                 ach = flops / avg_s / 1e12
                 peak = 2500.0 if a.fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
+                small_gru = (not a.fp16) and (not a.strict) and B <= int(os.environ.get("PERCEPNET_SMALL_GRU_ROWS", "1536"))
                 res["roofline"] = {
-                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else "pn_gru_mfma_p_kernel") + " (512->512 reset-after GRU step, 4 launches per frame)",
+                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else ("pn_gru_small_kernel" if small_gru else "pn_gru_mfma_p_kernel")) +
+                              " (512->512 reset-after GRU step, 4 launches per frame)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None if a.fp16 else traffic,
                     "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
