@@ -150,6 +150,7 @@ struct pn_ctx {
   bool profiling;
   struct Ev { int fam; hipEvent_t a, b; };
   std::vector<Ev> events;
+  std::vector<hipEvent_t> event_pool;   // recycled timing events: no hipEventCreate/Destroy inside a timed region
   double fam_ms[KF_COUNT]; int64_t fam_n[KF_COUNT];
   // pipelined host-buffer path (pn_submit_host_*): created on first use
   struct Pipe {
@@ -223,6 +224,7 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
     hipStreamDestroy(c->pipe.h2d); hipStreamDestroy(c->pipe.d2h);
   }
   for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -344,7 +346,10 @@ extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c
 struct Scope {
   pn_ctx *c; int fam; hipEvent_t a, b; bool on;
   Scope(pn_ctx *c_, int fam_) : c(c_), fam(fam_), on(c_->profiling) {
-    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    if (on) {
+      auto take = [&](hipEvent_t &e) { if (c->event_pool.empty()) hipEventCreate(&e); else { e = c->event_pool.back(); c->event_pool.pop_back(); } };
+      take(a); take(b); hipEventRecord(a, c->stream);
+    }
   }
   ~Scope() {
     if (on) { hipEventRecord(b, c->stream); c->events.push_back({fam, a, b}); }
@@ -359,13 +364,21 @@ static int flush_events(pn_ctx *c) {
   for (auto &e : c->events) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->fam_ms[e.fam] += ms; c->fam_n[e.fam]++; }
-    hipEventDestroy(e.a); hipEventDestroy(e.b);
+    c->event_pool.push_back(e.a); c->event_pool.push_back(e.b);
   }
   c->events.clear();
   return 0;
 }
 
-extern "C" int pn_ctx_set_profiling(pn_ctx *c, int enable) { if (!c) return -1; c->profiling = enable != 0; return 0; }
+extern "C" int pn_ctx_set_profiling(pn_ctx *c, int enable) {
+  if (!c) return -1;
+  if (enable && c->event_pool.size() < 2048) {        // enough for ~75 frames between two reads; created outside any timed region
+    PN_ON_DEVICE(c);
+    while (c->event_pool.size() < 2048) { hipEvent_t e; PN_HIP_CHECK(hipEventCreate(&e)); c->event_pool.push_back(e); }
+  }
+  c->profiling = enable != 0;
+  return 0;
+}
 extern "C" int pn_kernel_count(void) { return KF_COUNT; }
 extern "C" const char *pn_kernel_name(int i) { return (i >= 0 && i < KF_COUNT) ? kKernelNames[i] : NULL; }
 extern "C" int pn_ctx_kernel_time(pn_ctx *c, const char *name, double *total_ms, int64_t *launches) {

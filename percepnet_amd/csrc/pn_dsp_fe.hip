@@ -434,7 +434,10 @@ extern "C" int pn_fe_clocks_read(unsigned long long *out, int reset) {
 __device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
 
 template <typename TIn>
-__global__ __launch_bounds__(FE_THREADS, 1) void pn_frontend_kernel(
+#ifndef PN_FE_WAVES_PER_SIMD
+#define PN_FE_WAVES_PER_SIMD 1
+#endif
+__global__ __launch_bounds__(FE_THREADS, PN_FE_WAVES_PER_SIMD) void pn_frontend_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
     const TIn *__restrict__ in,           // stream s's frame at in + s*in_stride (480 contiguous samples)
     long long in_stride, float i16_scale, // int16 input: sample = (float)v * i16_scale (2^-15: main.cpp:34; 1: denoise.cpp:41,697)
