@@ -598,3 +598,42 @@ def test_small_batch_and_batch_gemm_kernel_families_agree_bit_for_bit(model, ora
     ro, rg, _, _ = oracle.run_batch(pcm, want_feat=False)
     assert np.abs(res["small"][0].astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
     assert np.abs(res["small"][1] - rg).max() <= GR_TOL
+
+
+def test_extreme_inputs_strict_bit_exact(model, oracle):
+    """Inputs at the edges of the int16 range: full-scale square wave, alternating +-32768/32767, a lone impulse, DC at
+    both rails, white noise at full scale.  The CLI's float->int16 conversion truncates and WRAPS (main.cpp:36, no
+    clamp), so overshoot of the synthesis window wraps around: STRICT mode must reproduce the oracle's PCM, tap, features
+    and silence flags bit for bit, MFMA mode within its tolerance on g/r (a wrapped sample may differ by 65535)."""
+    T = 30
+    n = T * 480
+    rng = np.random.default_rng(3)
+    t = np.arange(n)
+    x = np.stack([
+        np.where((t // 120) % 2 == 0, 32767, -32768),
+        np.where(t % 2 == 0, 32767, -32768),
+        np.where(t == 700, 32767, 0),
+        np.full(n, 32767), np.full(n, -32768),
+        rng.integers(-32768, 32768, n),
+        np.where((t // 4800) % 2 == 0, 0, rng.integers(-32768, 32768, n)),      # silence <-> full-scale noise every 10 frames
+    ]).astype(np.int16)
+    B = x.shape[0]
+    ro, rg, rf, rs = oracle.run_batch(x, threads=4)
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    out = np.zeros_like(ro); gr = np.zeros_like(rg)
+    for f in range(T):
+        o, g = ctx.process_i16(x[:, f * 480:(f + 1) * 480])
+        feat, sil = ctx.read_features()
+        assert np.array_equal(feat.view(np.uint32), rf[:, f].view(np.uint32)), f
+        assert np.array_equal(sil, rs[:, f]), f
+        gr[:, f] = g
+        if f > 0:
+            out[:, (f - 1) * 480:f * 480] = o
+    ctx.close()
+    assert np.array_equal(out, ro)
+    assert np.array_equal(gr.view(np.uint32), rg.view(np.uint32))
+    assert (rs == 0).any() and (rs == 1).any()
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    _, gm = ctx.run_pcm(x)
+    ctx.close()
+    assert np.abs(gm - rg).max() <= GR_TOL
