@@ -637,3 +637,37 @@ def test_extreme_inputs_strict_bit_exact(model, oracle):
     _, gm = ctx.run_pcm(x)
     ctx.close()
     assert np.abs(gm - rg).max() <= GR_TOL
+
+
+def test_maximum_size_batch_300k_streams(model, oracle):
+    """Far beyond the benchmarked batch: 300 007 concurrent streams (ragged, 22.7 GiB of state; 64-bit indexing, grid limits,
+    73 grid-stride rounds per front-end block) built from 16 distinct streams.  Every replica bit-identical wherever it
+    sits, the first 16 slots against the oracle (features bit-equal, g/r, PCM).  One million streams (75.5 GiB) passes the
+    same check: tools/big_batch_check.py, profiles/r02i_one_million_streams.log."""
+    import torch
+    B, T, P = 300007, 7, 16
+    base = synth.synth_batch(P, T)
+    ro, rg, rf, rs = oracle.run_batch(base, threads=8)
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(dev)
+    with torch.cuda.stream(ts):
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=ts.cuda_stream)
+        idx = torch.arange(B, device=dev) % P
+        dbase = torch.from_numpy(base).to(dev)
+        o = torch.empty((B, 480), dtype=torch.int16, device=dev); g = torch.empty((B, 68), dtype=torch.float32, device=dev)
+        f = torch.empty((B, 70), dtype=torch.float32, device=dev); s = torch.empty((B,), dtype=torch.int32, device=dev)
+        for t in range(T):
+            fr = dbase[:, t * 480:(t + 1) * 480][idx].contiguous()
+            ctx.process_i16_dev(fr.data_ptr(), o.data_ptr(), g.data_ptr())
+            ctx.read_features_dev(f.data_ptr(), s.data_ptr())
+            assert bool((o == o[:P][idx]).all()), (t, "pcm replicas")
+            assert bool((g.view(torch.int32) == g[:P][idx].view(torch.int32)).all()), (t, "g/r replicas")
+            assert bool((f.view(torch.int32) == f[:P][idx].view(torch.int32)).all()), (t, "feature replicas")
+            assert np.array_equal(f[:P].cpu().numpy().view(np.uint32), rf[:, t].view(np.uint32)), (t, "features vs oracle")
+            assert np.array_equal(s[:P].cpu().numpy(), rs[:, t])
+            assert np.abs(g[:P].cpu().numpy() - rg[:, t]).max() <= GR_TOL
+            if t > 0:
+                assert np.abs(o[:P].cpu().numpy().astype(np.int32) - ro[:, (t - 1) * 480:t * 480].astype(np.int32)).max() <= PCM_TOL_LSB
+        ctx.close()
+    del o, g, f, s, dbase
+    torch.cuda.empty_cache()
