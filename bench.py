@@ -7,8 +7,10 @@ Inputs (int16 PCM, the CLI's format) are resident in HBM before the timed region
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL only for
-the start/stop barrier and the max-over-ranks time — streams are independent, weak scaling).
+N > 1: `python bench.py --gpus N` launches its own N ranks through torch.distributed.run (one rank per GPU); when
+the driver launches the ranks itself (WORLD_SIZE/RANK in the environment) the script joins that world instead.
+RCCL is used only for the start/stop barrier, the max-over-ranks time and the report gather — streams are
+independent, weak scaling.  `--force-dist` makes an N = 1 run go through the same RCCL calls (world of one).
 
 Workload choice (config.workload): BASELINE.json's metric is a CAPACITY ("real-time 48 kHz
 streams per GPU", target >= 50 k), which only configs[2] (65 536 concurrent streams per GPU, the
@@ -127,20 +129,26 @@ def cpu_baseline(budget=8.0):
     }
 
 
-KERNEL_SOURCES = ("pn_nn.hip", "pn_nn_common.h", "pn_dsp_fe.hip", "pn_dsp.hip", "pn_context.cpp")
+def kernel_sources():
+    """Every file a kernel is compiled from: all .hip / .h / .inc under csrc/ (any depth) + the launch sequence."""
+    csrc = os.path.join(ROOT, "percepnet_amd", "csrc")
+    out = []
+    for d, _, fs in sorted(os.walk(csrc)):
+        out += [os.path.join(d, f) for f in sorted(fs) if f.endswith((".hip", ".h", ".inc")) or f == "pn_context.cpp"]
+    return out
 
 
 def kernels_snapshot():
-    """Identity of the kernels a profile was taken with: sha256 over the kernel sources (first 12 hex digits).
+    """Identity of the kernels a profile was taken with: sha256 over every kernel source (first 12 hex digits).
     tools/summarize_prof.py stamps it into profiles/*_pmc_per_launch.csv; a CSV from other kernels is refused."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "percepnet_amd", "csrc", f), "rb").read())
+    for f in kernel_sources():
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:12]
 
 
-def pmc_traffic_bytes(streams):
+def pmc_traffic_bytes(streams, kernel_prefix="pn_gru_mfma", tag=""):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
     this same command (profiles/*_pmc_per_launch.csv; FETCH_SIZE and WRITE_SIZE are collected in
     separate --pmc runs, both in KB).  Per MI355X_MICROARCH.md the gfx950 FETCH_SIZE counts 64 B
@@ -149,15 +157,17 @@ def pmc_traffic_bytes(streams):
     accepted (a profile of other kernels says nothing about this run): -> (bytes | None, source note)."""
     import csv, glob
     snap = kernels_snapshot()
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_launch.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_per_launch{tag}.csv")))
     fresh = [f for f in files if open(f).readline().strip() == f"# kernels_snapshot={snap}"]
     if not fresh:
         return None, f"no PMC profile of kernels snapshot {snap} under profiles/ (tools/gpu_profile.sh + tools/summarize_prof.py)"
-    grid = f"grid={((streams + 127) // 128 + 7) // 8 * 8 * 16 * 256}"
     fetch = write = None
     rows = [l for l in open(fresh[-1]) if not l.startswith("#")]
-    for r in csv.DictReader(rows):
-        if r["kernel"].startswith("pn_gru_mfma") and r["kernel"].endswith(grid):
+    recs = [r for r in csv.DictReader(rows) if r["kernel"].startswith(kernel_prefix)]
+    grids = sorted({int(r["kernel"].rsplit("grid=", 1)[1]) for r in recs if "grid=" in r["kernel"]})
+    grid = f"grid={grids[-1]}" if grids else "grid=?"        # the 512->512 layers are the largest grid of the family
+    for r in recs:
+        if r["kernel"].endswith(grid):
             if r["counter"] == "FETCH_SIZE":
                 fetch = float(r["avg"]) * 1024 * 2
             elif r["counter"] == "WRITE_SIZE":
@@ -200,10 +210,68 @@ def measure_parity(ctx, frames, pool_pcm, out, torch):
             "long_horizon": "tests/test_gpu_longrun.py: 1024 streams x 1000 frames and 256 sampled of 65536 x 1000 frames"}
 
 
-def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label):
+def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
+    """The roofline object of the dominant kernel (the 512->512 GRU step, 4 launches per frame) from HIP-event kernel
+    times `kt` of a context described by `desc` (Context.describe())."""
+    ms, n = kt.get("gru512", (0.0, 0))
+    if not n:
+        return None
+    avg_s = ms / n * 1e-3
+    flops = B * GRU512_FLOP_PER_STREAM_FRAME
+    kname = "pn_gru_f16_kernel" if fp16 else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel")
+    traffic, traffic_src = pmc_traffic_bytes(B, kname[:11], traffic_tag)
+    ach = flops / avg_s / 1e12
+    peak = 2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
+    r = {"kernel": kname + " (512->512 reset-after GRU step, 4 launches per frame)",
+         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(ach / peak, 4), "traffic": traffic,
+         "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
+         "algorithmic_bytes_per_launch": 3 * B * 512 * (2 if fp16 else 4) + (B * 512 * 4 if fp16 else 0) + 2 * 512 * 1536 * (2 if fp16 else 4),
+         "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4)}
+    if fps is not None:
+        r["whole_pipeline_tflops"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2)
+        r["whole_pipeline_frac_of_mfma_peak"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / peak, 4)
+        r["algorithmic_hbm_gbs"] = round(fps / n_gpus * (62608 + 31850256 / B) / 1e9, 1)
+    return r
+
+
+def dsp_roofline(kt, B):
+    """HBM roofline of the DSP kernels (front end = every kernel family whose name starts with "fe_" or "frontend",
+    back end): algorithmic bytes per stream-frame from DESIGN.md §4.1 / SURVEY §8(d)."""
+    fe_ms = sum(v[0] / max(v[1], 1) for k, v in kt.items() if k.startswith(("frontend", "fe_")))
+    be = kt.get("backend", (0.0, 0))
+    out = {}
+    if fe_ms > 0:
+        by = B * (27 * 1024 + 9 * 1024)           # ~27 KB read + 9 KB written per stream-frame
+        out["frontend"] = {"bound": "hbm", "ms": round(fe_ms, 4), "achieved": round(by / (fe_ms * 1e-3) / 1e9, 1),
+                           "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(by / (fe_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                           "algorithmic_bytes": by}
+    if be[1]:
+        ms = be[0] / be[1]
+        by = B * (3200 * 2 + 272 + 1920 * 2 + 960)  # X, P spectra; g|r; synthesis memory r/w; int16 PCM out
+        out["backend"] = {"bound": "hbm", "ms": round(ms, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                          "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                          "algorithmic_bytes": by}
+    return out
+
+
+def gpu_clock_mhz():
+    """Current shader clock (MHz) as rocm-smi reports it, or None."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"sclk clock level:?\s*\S*\s*\(?(\d+)\s*Mhz", out, re.I)
+        return int(m.group(1)) if m else None
+    except Exception:                         # noqa: BLE001 — a missing tool must not cost the bench line
+        return None
+
+
+def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, traffic_tag):
     """One of BASELINE's OTHER single-GPU configurations, timed the same way as the headline (W warm-up steps, K timed
     steps between synchronisations, inputs resident, no per-kernel events) and checked against the oracle on its own
-    batch — reported under "other_configs", never as `value`."""
+    batch — reported under "other_configs", never as `value`.  A second, separately timed pass with per-kernel HIP
+    events gives the configuration its own roofline object."""
     T = K + W
     P = min(B, 64)
     pool_np = synth.synth_batch(P, T, base_seed=synth.BASE_SEED + 104729)
@@ -224,17 +292,61 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         par = measure_parity(ctx, frames, pool_np, out, torch)
+        ctx.reset_profile(); ctx.set_profiling(True)
+        for t in range(min(T, 40)):
+            ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
+        torch.cuda.synchronize()
+        ctx.set_profiling(False)
+        kt = ctx.kernel_times()
+        desc = ctx.describe()
     finally:
         ctx.close()
     return {"workload": label, "streams_per_gpu": B, "steps": K, "warmup": W, "value": round(B * K / dt / 100.0, 1),
             "unit": "streams", "ms_per_step": round(1e3 * dt / K, 4),
             "max_abs_delta_vs_cpu_ref_lsb": par["max_abs_delta_vs_cpu_ref_lsb"], "max_abs_delta_gr": par["max_abs_delta_gr"],
-            "pcm_samples_checked": par["pcm_samples_checked"], "replay_bit_identical": par["replay_of_timed_run_bit_identical"]}
+            "pcm_samples_checked": par["pcm_samples_checked"], "replay_bit_identical": par["replay_of_timed_run_bit_identical"],
+            "kernel_families": desc,
+            "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
+            "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, traffic_tag=traffic_tag),
+            "dsp_roofline": dsp_roofline(kt, B)}
+
+
+def drop_in_single_stream(frames=1000):
+    """ms per frame of the reference's own UNTOUCHED main.cpp relinked against this library (INTEGRATION.md level 1:
+    one rnnoise_process_frame per frame = the launch sequence + two PCIe hops + a synchronise, /root/reference/src/
+    main.cpp:30-39), from the difference of two file lengths so that process start and context creation cancel."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from percepnet_amd import synth
+    exe = os.path.join(ROOT, "percepnet_amd", "lib", "percepNet_run_relinked")
+    if not os.path.exists(exe):
+        return None
+    from percepnet_amd import weights
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "m.pnw"), "wb").write(weights.default_blob(1234))
+        env = dict(os.environ, PERCEPNET_MODEL=os.path.join(d, "m.pnw"))
+        times = {}
+        for n in (100, 100 + frames):
+            pcm = synth.synth_stream(5, n)
+            np.asarray(pcm, dtype="<i2").tofile(os.path.join(d, f"in{n}.pcm"))
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, f"in{n}.pcm", f"out{n}.pcm"], cwd=d, env=env, capture_output=True, timeout=300)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0 or b"INERT" in r.stderr:
+                    return {"error": r.stderr.decode(errors="replace")[-300:]}
+                best = dt if best is None else min(best, dt)
+            times[n] = best
+    return {"ms_per_frame": round(1e3 * (times[100 + frames] - times[100]) / frames, 4), "frames": frames,
+            "what": "lib/percepNet_run_relinked (reference main.cpp, untouched) on one stream: wall(1100 frames) - wall(100 frames)",
+            "wall_s": {str(k): round(v, 3) for k, v in times.items()}}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launched world, else 1")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=65536, help="concurrent streams per GPU")
@@ -243,17 +355,26 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the measured max|delta| vs the CPU oracle")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short side measurements of configs[1] (1024 streams) and configs[4] (fp16) at N = 1")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained-rate loop after the timed region")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
     ap.add_argument("--fp16", action="store_true",
                     help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: <=3 LSB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 through torch.distributed.run too: the RCCL init, barriers, all-reduces and gather of the N > 1 path")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     a = ap.parse_args()
 
     from percepnet_amd import sharding
     rank, local_rank, world = sharding.launched_world()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    launched = sharding.launched_by_torchrun()
+    if a.gpus is None:
+        a.gpus = world if launched else 1
+        if launched and world > 1:
+            print(f"[bench] --gpus not given: adopting the launched world of {world} rank(s)", file=sys.stderr, flush=True)
+    if not launched and (a.gpus > 1 or a.force_dist):
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
         sys.exit(sharding.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
@@ -274,11 +395,12 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = sharding.init_ranks(a.backend, a.gpus, dev)       # refuses WORLD_SIZE != --gpus
+    dist = sharding.init_ranks(a.backend, a.gpus, dev)       # refuses WORLD_SIZE != --gpus; joins a world of one too
     n_gpus = world
 
     B, K, W = a.streams, a.steps, a.warmup
-    print(f"[bench] rank {rank}/{world} B={B} K={K} W={W}", file=sys.stderr, flush=True)
+    print(f"[bench] rank {rank}/{world} B={B} K={K} W={W} dist={'none' if dist is None else dist.get_backend()}",
+          file=sys.stderr, flush=True)
     T = K + W
     blob = weights.default_blob(1234)
     model = api.Model(blob)
@@ -338,6 +460,7 @@ def main():
         parity = None
         if not a.no_parity and not a.strict:
             parity = measure_parity(ctx, frames, pool_np, out, torch)
+        desc = ctx.describe()
         res = {
             "metric": "real-time 48 kHz streams (10 ms frames), whole job",
             "value": round(fps / 100.0, 1),
@@ -356,6 +479,8 @@ def main():
                 "weights": "torch.manual_seed(1234) default-init PercepNet in nnet_data.h layout",
                 "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective",
                 "io": "int16 PCM resident in HBM",
+                "kernel_families": desc,
+                "distributed": "none (plain process)" if dist is None else f"torch.distributed {dist.get_backend()} world {dist.get_world_size()}",
             },
             "ranks": rep["ranks"],
             "per_gpu_frames_per_s": [r["fps"] for r in rep["ranks"]],
@@ -369,42 +494,47 @@ def main():
         if kt:
             per = {k: {"ms_avg": round(v[0] / max(v[1], 1), 4), "launches": v[1]} for k, v in kt.items()}
             res["kernels"] = per
-            ms, n = kt.get("gru512", (0.0, 0))
-            if n:
-                avg_s = ms / n * 1e-3
-                flops = B * GRU512_FLOP_PER_STREAM_FRAME
-                traffic, traffic_src = pmc_traffic_bytes(B)
-                ach = flops / avg_s / 1e12
-                peak = 2500.0 if a.fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
-                small_gru = (not a.fp16) and (not a.strict) and B <= int(os.environ.get("PERCEPNET_SMALL_GRU_ROWS", "1536"))
-                res["roofline"] = {
-                    "kernel": ("pn_gru_f16_kernel" if a.fp16 else ("pn_gru_small_kernel" if small_gru else "pn_gru_mfma_p_kernel")) +
-                              " (512->512 reset-after GRU step, 4 launches per frame)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None if a.fp16 else traffic,
-                    "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
-                    "algorithmic_bytes_per_launch": 3 * B * 512 * 4 + 2 * 512 * 1536 * 4,   # x, h read; h' written; W,U once
-                    "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4),
-                    "whole_pipeline_tflops": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2),
-                    "whole_pipeline_frac_of_mfma_peak": round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / peak, 4),
-                    "algorithmic_hbm_gbs": round(fps / n_gpus * (62608 + 31850256 / B) / 1e9, 1),
-                }
+            tag = "_fp16" if a.fp16 else ("" if B == 65536 else f"_{B}")
+            rl = gru_roofline(kt, B, a.fp16, desc, n_gpus, fps, traffic_tag=tag)
+            if rl:
+                res["roofline"] = rl
+            res["dsp_roofline"] = dsp_roofline(kt, B)
         if cpu is not None:
             res["cpu_baseline"] = cpu
+        # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
+        # are 0.2 s, shorter than the time the chip needs to settle on its power-limited clock.
+        if world == 1 and not a.no_sustained and not a.strict:
+            n_sus = max(K, int(a.sustained_seconds / max(dt / K, 1e-6)) + 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_sus):
+                ctx.process_i16_dev(frames[i % T].data_ptr(), out.data_ptr(), None)
+            torch.cuda.synchronize()
+            ds = time.perf_counter() - t0
+            res["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 4),
+                                "value": round(B * n_sus / ds / 100.0, 1), "unit": "streams",
+                                "sclk_mhz_at_end": gpu_clock_mhz(),
+                                "note": "no per-kernel events in this loop; the K-step figure above is the contract's"}
         # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
         # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
         # Only with the default headline workload at N = 1; a failure here never costs the headline line.
         if world == 1 and B == 65536 and not (a.fp16 or a.strict or a.no_other_configs or a.no_parity):
             other = {}
-            for key, (b2, k2, w2, mode2, label) in {
-                    "configs[1]": (1024, 200, 20, api.NN_MFMA, "1024 concurrent streams, fp32 (small-batch kernel family)"),
-                    "configs[4]": (65536, 20, 3, api.NN_MFMA_F16, "65536 concurrent streams, fp16 GEMM operands, fp32 accumulate/state/DSP"),
+            for key, (b2, k2, w2, mode2, label, ttag) in {
+                    "configs[1]": (1024, 200, 20, api.NN_MFMA, "1024 concurrent streams, fp32 (small-batch kernel family)", "_1024"),
+                    "configs[4]": (65536, 20, 3, api.NN_MFMA_F16, "65536 concurrent streams, fp16 GEMM operands, fp32 accumulate/state/DSP", "_fp16"),
             }.items():
                 try:
-                    other[key] = side_config(api, synth, torch, model, dev, stream, b2, k2, w2, mode2, label)
+                    other[key] = side_config(api, synth, torch, model, dev, stream, b2, k2, w2, mode2, label, ttag)
                 except Exception as e:          # noqa: BLE001 — reported, not fatal
                     other[key] = {"workload": label, "error": f"{type(e).__name__}: {e}"}
             res["other_configs"] = other
+            try:
+                res["drop_in_single_stream"] = drop_in_single_stream()
+                if cpu is not None and res["drop_in_single_stream"] and "ms_per_frame" in res["drop_in_single_stream"]:
+                    res["drop_in_single_stream"]["cpu_reference_ms_per_frame_one_core"] = round(1e3 / cpu["frames_per_s_one_core"], 4)
+            except Exception as e:              # noqa: BLE001
+                res["drop_in_single_stream"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
     ctx.close()
     model.close()

@@ -53,6 +53,7 @@ def load_library():
     L.pn_ctx_frames_done.argtypes = [_vp]
     L.pn_ctx_device_bytes.restype = ctypes.c_size_t
     L.pn_ctx_device_bytes.argtypes = [_vp]
+    L.pn_ctx_describe.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
     for name in ("pn_process_f32", "pn_process_i16", "pn_process_host_f32", "pn_process_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
@@ -154,6 +155,13 @@ class Context:
 
     def device_bytes(self):
         return self.L.pn_ctx_device_bytes(self.h)
+
+    def describe(self):
+        """{"nn": ..., "dense": "small"|"batch", "gru": ..., "gru_rb": ..., "frontend": ...}: the kernel families in use."""
+        buf = ctypes.create_string_buffer(256)
+        if self.L.pn_ctx_describe(self.h, buf, len(buf)) < 0:
+            raise PercepNetError("pn_ctx_describe failed")
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
     # device-pointer entry points (ints, e.g. torch.Tensor.data_ptr())
     def process_i16_dev(self, d_in, d_out, d_gr=None):

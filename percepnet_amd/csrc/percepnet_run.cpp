@@ -12,6 +12,7 @@
 // pinned buffers, and the threads never talk to each other — the one-process counterpart of the reference's shell
 // fan-out (utils/run.sh:49,65,99).  No collective is involved.
 #include "../../include/percepnet_hip.h"
+#include "pn_cli_util.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,25 +24,45 @@ extern const RNNModel percepnet_model_orig __attribute__((weak));
 
 struct Shard { int device, first, count, rc; std::string err; };
 
+// Everything a shard holds; released on every exit path of run_shard.
+struct ShardRes {
+  pn_ctx *cx = NULL;
+  std::vector<FILE *> fin, fout;
+  FILE *ftap = NULL;
+  struct Slot { int16_t *in = NULL, *out = NULL; float *gr = NULL; std::vector<char> alive; } slot[3];
+  ~ShardRes() {
+    for (auto &sl : slot) { pn_host_free(sl.in); pn_host_free(sl.out); pn_host_free(sl.gr); }
+    for (FILE *f : fin) if (f) fclose(f);
+    for (FILE *f : fout) if (f) fclose(f);
+    if (ftap) fclose(ftap);
+    pn_ctx_destroy(cx);
+  }
+};
+
 // One device: pairs [first, first+count) of argv-style (in, out) paths as `count` concurrent streams.
 static void run_shard(Shard *sh, const pn_model *m, char **paths, int strict, int postfilter, bool tap) {
   const int B = sh->count;
   auto fail = [&](int rc, const std::string &msg) { sh->rc = rc; sh->err = msg; };
-  pn_ctx *cx = pn_ctx_create(m, sh->device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
+  ShardRes R;
+  R.cx = pn_ctx_create(m, sh->device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
+  pn_ctx *cx = R.cx;
   if (!cx) return fail(3, std::string("pn_ctx_create: ") + pn_last_error());
   if (postfilter) pn_ctx_set_postfilter(cx, 1);
-  std::vector<FILE *> fin(B), fout(B);
+  std::vector<FILE *> &fin = R.fin, &fout = R.fout;
+  fin.assign(B, NULL); fout.assign(B, NULL);
   for (int s = 0; s < B; s++) {
     const char *pi = paths[2 * (sh->first + s)], *po = paths[2 * (sh->first + s) + 1];
     fin[s] = fopen(pi, "rb"); fout[s] = fopen(po, "wb");
     if (!fin[s] || !fout[s]) return fail(4, std::string("cannot open ") + pi + " / " + po);
   }
-  FILE *ftap = tap ? fopen("feature_test.raw", "wb") : NULL;
+  R.ftap = tap ? fopen("feature_test.raw", "wb") : NULL;
+  FILE *ftap = R.ftap;
   // Three rotating pinned buffer sets on the pipelined entry point: the files of frame t+1 are read while the GPU
   // works on frame t, and frame t-2's output is on the host once pn_submit_host_i16(t) has returned.
-  struct Slot { int16_t *in, *out; float *gr; std::vector<char> alive; };
-  Slot slot[3];
-  for (Slot &sl : slot) {
+  typedef ShardRes::Slot Slot;
+  Slot *slot = R.slot;
+  for (int k = 0; k < 3; k++) {
+    Slot &sl = slot[k];
     sl.in = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
     sl.out = (int16_t *)pn_host_alloc((size_t)B * PN_FRAME_SIZE * sizeof(int16_t));
     sl.gr = (float *)pn_host_alloc((size_t)B * 68 * sizeof(float));
@@ -73,10 +94,6 @@ static void run_shard(Shard *sh, const pn_model *m, char **paths, int strict, in
   }
   if (pn_host_wait(cx)) return fail(5, pn_last_error());
   for (long u = (t >= 2 ? t - 2 : 0); u < t; u++) flush(slot[u % 3]);     // the last two frames in flight
-  for (Slot &sl : slot) { pn_host_free(sl.in); pn_host_free(sl.out); pn_host_free(sl.gr); }
-  for (int s = 0; s < B; s++) { fclose(fin[s]); fclose(fout[s]); }
-  if (ftap) fclose(ftap);
-  pn_ctx_destroy(cx);
 }
 
 int main(int argc, char **argv) {
@@ -89,11 +106,10 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
     else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) devices.assign(1, atoi(argv[++ai]));
     else if (!strcmp(argv[ai], "--devices") && ai + 1 < argc) {
-      const char *s = argv[++ai];
-      devices.clear();
-      if (!strcmp(s, "all")) { const int n = pn_device_count(); for (int d = 0; d < n; d++) devices.push_back(d); }
-      else for (const char *p = s; *p;) { devices.push_back((int)strtol(p, (char **)&p, 10)); if (*p == ',') p++; else if (*p) { devices.clear(); break; } }
-      if (devices.empty()) { fprintf(stderr, "--devices: expected a comma-separated list of device ordinals or 'all' (%d device(s) visible)\n", pn_device_count()); return 1; }
+      if (!pn_cli_parse_devices(argv[++ai], pn_device_count(), devices)) {
+        fprintf(stderr, "--devices: expected a comma-separated list of device ordinals in [0,%d) or 'all', got '%s'\n", pn_device_count(), argv[ai]);
+        return 1;
+      }
     }
     else break;
   }
@@ -113,8 +129,9 @@ int main(int argc, char **argv) {
   const int W = (int)devices.size() < B ? (int)devices.size() : B;
   std::vector<Shard> shards(W);
   for (int r = 0; r < W; r++) {
-    const int base = B / W, rem = B % W;
-    shards[r] = {devices[r], r * base + (r < rem ? r : rem), base + (r < rem ? 1 : 0), 0, ""};
+    int first, count;
+    pn_cli_shard(B, W, r, &first, &count);
+    shards[r] = {devices[r], first, count, 0, ""};
   }
   const bool tap = B == 1;
   if (W == 1) run_shard(&shards[0], m, argv + ai, strict, postfilter, tap);
@@ -126,6 +143,10 @@ int main(int argc, char **argv) {
   int rc = 0;
   for (const Shard &sh : shards)
     if (sh.rc) { fprintf(stderr, "device %d (pairs %d..%d): %s\n", sh.device, sh.first, sh.first + sh.count - 1, sh.err.c_str()); if (sh.rc > rc) rc = sh.rc; }
+  if (rc && W > 1)         // some shards may have finished: say which outputs are complete and which are not
+    for (const Shard &sh : shards)
+      fprintf(stderr, "  outputs of pairs %d..%d (device %d): %s\n", sh.first, sh.first + sh.count - 1, sh.device,
+              sh.rc ? "INCOMPLETE - discard" : "complete");
   pn_model_free(m);
   return rc;
 }

@@ -340,6 +340,14 @@ extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); if 
 extern "C" int pn_ctx_n_streams(const pn_ctx *c) { return c ? c->B : -1; }
 extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
 extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
+extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
+  if (!c || !buf || !n) return -1;
+  const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : "mfma_f32");
+  const bool fam = c->nn_mode == PN_NN_MFMA;            // the small-batch family exists for the fp32 MFMA mode only
+  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
+                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch", c->fe_g2 ? "g2" : "g4");
+  return (w < 0 || (size_t)w >= n) ? -1 : w;
+}
 extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
 
 // ---- profiling ------------------------------------------------------------------------------------------

@@ -92,8 +92,20 @@ float rnnoise_process_frame(DenoiseState *st, float *out, const float *in, FILE 
 // compiler emits _Z11compute_rnnP8RNNStatePfS1_PKf).  The state lives in the caller's host arrays as in the reference;
 // each call uploads it to a batch-of-one context cached per model, runs the ten layers on the GPU and writes the new
 // state back.  Correct but launch- and PCIe-bound by construction — batched callers use pn_ctx_compute_rnn_host.
+// The cache is keyed on the RNNModel's address; rnnoise_model_free drops the entry (a new model allocated at a freed
+// address must not run with the old weights); a failed creation is retried on the next call, not cached.
+// PERCEPNET_DEVICE / PERCEPNET_STRICT are read when an entry is created.  Entries of models that are never freed (the
+// link-time percepnet_model_orig) live until process exit: tearing HIP objects down from a library destructor races the
+// HIP runtime's own exit handlers, so that is deliberately left to the OS.
 static std::mutex g_rnn_mu;
-static std::map<const RNNModel *, std::pair<pn_model *, pn_ctx *>> g_rnn_ctx;
+struct RnnEntry { pn_model *m; pn_ctx *c; };
+static std::map<const RNNModel *, RnnEntry> g_rnn_ctx;
+static void rnn_cache_drop(const RNNModel *key) {          // caller holds g_rnn_mu
+  auto it = g_rnn_ctx.find(key);
+  if (it == g_rnn_ctx.end()) return;
+  pn_ctx_destroy(it->second.c); pn_model_free(it->second.m);
+  g_rnn_ctx.erase(it);
+}
 
 void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *input) {
   if (!rnn || !rnn->model || !gains || !strengths || !input) return;
@@ -102,10 +114,15 @@ void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *inp
   if (it == g_rnn_ctx.end()) {
     pn_model *m = pn_model_from_rnnmodel(rnn->model);
     pn_ctx *c = m ? pn_ctx_create(m, env_device(), 1, env_mode(), NULL) : NULL;
-    if (!c) fprintf(stderr, "percepnet_hip: compute_rnn: %s (no CPU fallback: outputs are zero)\n", pn_last_error());
-    it = g_rnn_ctx.emplace(rnn->model, std::make_pair(m, c)).first;
+    if (!c) {                                              // not cached: the next call tries again
+      fprintf(stderr, "percepnet_hip: compute_rnn: %s (no CPU fallback: outputs are zero)\n", pn_last_error());
+      pn_model_free(m);
+      memset(gains, 0, 34 * sizeof(float)); memset(strengths, 0, 34 * sizeof(float));
+      return;
+    }
+    it = g_rnn_ctx.emplace(rnn->model, RnnEntry{m, c}).first;
   }
-  pn_ctx *c = it->second.second;
+  pn_ctx *c = it->second.c;
   float gr[68];
   if (!c ||
       pn_ctx_set_rnn_state_host(c, rnn->first_conv1d_state, rnn->second_conv1d_state, rnn->gru1_state, rnn->gru2_state,
@@ -160,6 +177,7 @@ RNNModel *rnnoise_model_from_file(FILE *f) {
 
 void rnnoise_model_free(RNNModel *model) {
   if (!model) return;
+  { std::lock_guard<std::mutex> lk(g_rnn_mu); rnn_cache_drop(model); }   // a later model at this address starts clean
   OwnedModel *o = (OwnedModel *)model;
   free(o->data); free(o);
 }

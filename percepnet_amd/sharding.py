@@ -43,14 +43,21 @@ def spawn_ranks(n_ranks, script, script_args, timeout=None, env=None):
     return subprocess.run(cmd, env=e, timeout=timeout).returncode
 
 
+def launched_by_torchrun():
+    """True when this process was started by torch.distributed.run (it exports RANK and WORLD_SIZE, also for one rank)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
 def init_ranks(backend, expected_world, device=None):
-    """Join the process group when launched with WORLD_SIZE > 1 and REFUSE a world that is not the one asked for:
-    a report must never say n_gpus = N unless N ranks really ran and synchronised.  Returns torch.distributed or None."""
+    """Join the process group whenever this process was launched by torch.distributed.run — ALSO for a world of one, so
+    that a 1-GPU box runs the very same RCCL calls (init, barriers, all-reduces, object gather) as the 8-GPU run — and
+    REFUSE a world that is not the one asked for: a report must never say n_gpus = N unless N ranks really ran and
+    synchronised.  expected_world None = adopt the launched world.  Returns torch.distributed or None (plain process)."""
     rank, _, world = launched_world()
-    if expected_world != world:
+    if expected_world is not None and expected_world != world:
         raise SystemExit(f"asked for {expected_world} rank(s) but launched with WORLD_SIZE={world}: refusing to "
                          f"report a world that did not run")
-    if world == 1:
+    if not launched_by_torchrun():
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,7 +94,7 @@ def timed_steps(dist, step, warmup, steps, sync):
 def aggregate_throughput(dist, my_stream_frames, my_seconds):
     """-> (whole-job stream-frames per second, max-over-ranks seconds).  `dist` is
     torch.distributed (initialised) or None for a single process."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return my_stream_frames / my_seconds, my_seconds
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"   # gloo reduces host tensors

@@ -23,8 +23,12 @@ def _bench(*args):
 
 
 def test_single_rank_line_has_measured_parity_and_roofline():
-    r = _bench("--streams", "2048", "--steps", "8", "--warmup", "2", "--no-cpu-baseline")
+    r = _bench("--streams", "2048", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--sustained-seconds", "0.3")
     assert r["n_gpus"] == 1 and len(r["ranks"]) == 1
+    assert r["config"]["distributed"].startswith("none")
+    assert r["sustained"]["steps"] >= 8 and r["sustained"]["seconds"] >= 0.3 and r["sustained"]["value"] > 0
+    assert r["config"]["kernel_families"]["gru"] == "batch" and r["config"]["kernel_families"]["dense"] == "small"   # 2048 streams
+    assert r["dsp_roofline"]["frontend"]["bound"] == "hbm" and 0 < r["dsp_roofline"]["frontend"]["frac"] < 1
     assert isinstance(r["max_abs_delta_vs_cpu_ref_lsb"], int) and r["max_abs_delta_vs_cpu_ref_lsb"] <= 1
     assert r["max_abs_delta_gr"] <= 2e-5
     assert r["parity"]["replay_of_timed_run_bit_identical"] is True
@@ -39,3 +43,30 @@ def test_two_ranks_self_launched():
     assert all(x["stream_frames"] == 1024 * 5 for x in r["ranks"])
     assert abs(r["frames_per_s"] - 2 * 1024 * 5 / (r["ms_per_step"] * 5e-3)) < 1e-3 * r["frames_per_s"]
     assert "cpu_baseline" not in r                       # only at N = 1
+
+
+def test_world_of_one_runs_the_rccl_path():
+    """The N > 1 code path on the hardware this box has: `--force-dist` launches ONE rank through torch.distributed.run,
+    which joins an RCCL ("nccl") process group bound to its device and goes through both barriers, both CUDA-tensor
+    all-reduces and the object gather of sharding.py — the calls `bench.py --gpus 8` makes, first executed here and not
+    inside the 8-GPU run.  Same work as the plain process: same checksum, rate within noise."""
+    common = ("--streams", "2048", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-sustained", "--no-parity")
+    d = _bench("--force-dist", *common)
+    assert d["n_gpus"] == 1 and len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0
+    assert d["config"]["distributed"] == "torch.distributed nccl world 1"
+    p = _bench(*common)
+    assert p["config"]["distributed"].startswith("none")
+    assert d["checksum"] == p["checksum"]
+    assert 0.6 < d["value"] / p["value"] < 1.6, (d["value"], p["value"])
+
+
+def test_launched_world_is_adopted_without_the_flag():
+    """torch.distributed.run --nproc-per-node=1 bench.py (no --gpus): the launched world is adopted, not refused."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--streams", "1024", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-sustained", "--no-parity"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["config"]["distributed"] == "torch.distributed nccl world 1"
+

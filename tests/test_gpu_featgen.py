@@ -154,3 +154,17 @@ def test_train_symbol_and_cli_file_semantics(oracle, tmp_path):
         pcm = np.fromfile(str(tmp_path / f"cli{p}.f32") + ".test_output.pcm", np.int16).reshape(counts[p], 480)
         _check(rec, pcm, orec, opcm)
     assert subprocess.run([exe, "a", "b"], capture_output=True).returncode == 1
+    # multi-device host (SURVEY 8(f)1 / run.sh:95-117's fan-out): --devices shards the jobs over one host thread + one
+    # generator per listed device; the same device twice on this 1-GPU box = two threads, ragged shards of 2 + 1 jobs.
+    # The records must be byte-identical to the single-device run.
+    args2 = [exe, "--devices", "0,0", "--test-pcm"]
+    for p in range(3):
+        args2 += [paths[p][0], paths[p][1], str(counts[p]), str(tmp_path / f"md{p}.f32")]
+    subprocess.run(args2, check=True, timeout=300)
+    for p in range(3):
+        assert (tmp_path / f"md{p}.f32").read_bytes() == (tmp_path / f"cli{p}.f32").read_bytes(), p
+        assert (tmp_path / f"md{p}.f32.test_output.pcm").read_bytes() == (tmp_path / f"cli{p}.f32.test_output.pcm").read_bytes(), p
+    for bad in ("0,,0", "0,", "x", "0,99"):              # an empty element is not device 0; an ordinal must be visible
+        r = subprocess.run([exe, "--devices", bad] + args2[4:], capture_output=True, text=True)
+        assert r.returncode == 1 and "--devices" in r.stderr, (bad, r.stderr)
+

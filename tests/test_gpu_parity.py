@@ -341,7 +341,10 @@ def test_cli_percepnet_run_matches_reference_cli_contract(blob, oracle, tmp_path
     assert r.returncode == 0, r.stderr
     for i, x in enumerate(ins):
         assert np.array_equal(np.fromfile(tmp_path / f"o{i}.pcm", np.int16), oracle.run_pcm(x)[0]), i
-    r = subprocess.run([exe, "--model", "m.pnw", "--devices", "0,7"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    for bad in ("0,7", "0,,0", "0,", "x"):     # not a visible ordinal / an empty element (never read as device 0) / not a number
+        r = subprocess.run([exe, "--model", "m.pnw", "--devices", bad] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and "--devices" in r.stderr, (bad, r.stderr)
+    r = subprocess.run([exe, "--model", "m.pnw", "--device", "7"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "device 7" in r.stderr and "out of range" in r.stderr       # a bad shard is reported, not hidden
 
 

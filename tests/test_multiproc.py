@@ -61,6 +61,17 @@ def test_two_rank_launch_timing_and_report(tmp_path):
     assert abs(r["dt0"] - rep["seconds"]) < 0.03                              # the closing barrier holds rank 0 for rank 1
 
 
+def test_world_of_one_still_joins_a_process_group(tmp_path):
+    """A single rank launched through torch.distributed.run joins a group of one and runs the same barriers,
+    all-reduces and object gather as N ranks (what `bench.py --force-dist` exercises with RCCL on a 1-GPU box)."""
+    out = _launch(tmp_path, 1, 1)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["rep"]["n_ranks"] == 1 and r["rep"]["ranks"][0]["ids"] == list(range(10))
+    assert r["calls"] == [0, 1, "timed", 2, 3, 4]
+    assert abs(r["rep"]["fps"] - 30 / r["rep"]["seconds"]) < 1e-6 * r["rep"]["fps"] + 1e-3
+
+
 def test_wrong_world_is_refused(tmp_path):
     out = _launch(tmp_path, 2, 3)               # asked for 3 ranks, launched 2: never report a world that did not run
     assert out.returncode != 0
