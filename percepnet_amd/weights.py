@@ -206,3 +206,130 @@ def default_blob(seed=1234, gain=1.0, cache_dir=None):
         os.replace(tmp, path)
     _CACHE[key] = blob
     return blob
+
+
+# ---- exporter: trained checkpoints / generated nnet_data.cpp -> PNW1 ------------------------------------------------
+# The reference's route from a trained model to the C engine is dump_percepnet.py:128-155: load the bare state_dict that
+# rnn_train.py:245,322 saves, print every array as C text into src/nnet_data.cpp, recompile.  Here both ends of that
+# route are accepted as inputs and the result is the binary container the engine loads at run time
+# (rnnoise_model_from_file / pn_model_from_file / percepnet_run --model):
+#     python -m percepnet_amd.weights --checkpoint model.pt -o model.pnw
+#     python -m percepnet_amd.weights --nnet-data src/nnet_data.cpp -o model.pnw
+_SD_PREFIX = {KIND_DENSE: "{}.0.", KIND_CONV1D: "{}.0.", KIND_GRU: "{}."}   # Sequential(Linear|Conv1d, act) vs bare GRU
+
+
+def layers_from_state_dict(sd):
+    """A rnn_train.PercepNet state_dict (name -> tensor / ndarray; a {"model": sd} / {"state_dict": sd} wrapper and a
+    DataParallel "module." prefix are unwrapped) -> layers in nnet_data.h layout, by the dumper's own transforms
+    (dump_percepnet.py:51-126)."""
+    for key in ("model", "state_dict", "model_state_dict"):
+        if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+            sd = sd[key]
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+    def arr(name):
+        if name not in sd:
+            raise KeyError(f"checkpoint has no '{name}' (not a rnn_train.PercepNet state_dict?)")
+        v = sd[name]
+        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return np.asarray(v, dtype=np.float32)
+
+    out = {}
+    for name, kind, nin, nn_, ks, act in LAYERS:
+        p = _SD_PREFIX[kind].format(name)
+        if kind == KIND_DENSE:
+            w, b, rec = arr(p + "weight").T, arr(p + "bias"), None
+            want = (nin, nn_)
+        elif kind == KIND_CONV1D:
+            w, b, rec = arr(p + "weight").transpose(2, 1, 0), arr(p + "bias"), None
+            want = (ks, nin, nn_)
+        else:
+            w = _gru_kernel_to_c(arr(p + "weight_ih_l0"))
+            rec = _gru_kernel_to_c(arr(p + "weight_hh_l0"))
+            b = _gru_bias_to_c(arr(p + "bias_ih_l0"), arr(p + "bias_hh_l0"))
+            want = (nin, 3 * nn_)
+        if tuple(w.shape) != want:
+            raise ValueError(f"{name}: weight shape {tuple(w.shape)} is not the PercepNet topology's {want} (rnn_train.py:105-121)")
+        d = {"bias": np.ascontiguousarray(b, dtype=np.float32).reshape(-1),
+             "input_weights": np.ascontiguousarray(w, dtype=np.float32).reshape(-1)}
+        if rec is not None:
+            d["recurrent_weights"] = np.ascontiguousarray(rec, dtype=np.float32).reshape(-1)
+        out[name] = d
+    return out
+
+
+_ACT_CODE = {"LINEAR": ACT_LINEAR, "SIGMOID": ACT_SIGMOID, "TANH": ACT_TANH, "RELU": ACT_RELU}
+
+
+def layers_from_nnet_data(text):
+    """The C text dump_percepnet.py writes (src/nnet_data.cpp) -> (layers, acts).  Every float literal is the exact
+    decimal expansion of a float32 ('{}'.format of a numpy float32, dump_percepnet.py:38), so float(literal) cast to
+    float32 is the identical value.  The layer records (`const DenseLayer fc = { fc_bias, fc_weights, 70, 128,
+    ACTIVATION_RELU };` ...) are checked against the topology and supply the activations."""
+    import re
+    arrays = {}
+    for m in re.finditer(r"static\s+const\s+float\s+(\w+)\s*\[\s*(\d+)\s*\]\s*=\s*\{(.*?)\}\s*;", text, re.S):
+        vals = np.array([float(v) for v in m.group(3).replace("\n", " ").split(",") if v.strip()], dtype=np.float64)
+        if vals.size != int(m.group(2)):
+            raise ValueError(f"{m.group(1)}: declared {m.group(2)} values, found {vals.size}")
+        arrays[m.group(1)] = vals.astype(np.float32)
+    recs = {m.group(2): (m.group(1), [t.strip() for t in m.group(3).split(",") if t.strip()])
+            for m in re.finditer(r"const\s+(DenseLayer|Conv1DLayer|GRULayer)\s+(\w+)\s*=\s*\{(.*?)\}\s*;", text, re.S)}
+    out, acts = {}, {}
+    ctype = {KIND_DENSE: "DenseLayer", KIND_CONV1D: "Conv1DLayer", KIND_GRU: "GRULayer"}
+    for name, kind, nin, nn_, ks, act in LAYERS:
+        if name not in recs or recs[name][0] != ctype[kind]:
+            raise ValueError(f"nnet_data text has no `const {ctype[kind]} {name}` record")
+        tok = recs[name][1]
+        if kind == KIND_DENSE:       # bias, weights, nb_inputs, nb_neurons, activation            (nnet.h:44-50)
+            b, w, rw, dims, a = tok[0], tok[1], None, (int(tok[2]), 1, int(tok[3])), tok[4]
+        elif kind == KIND_CONV1D:    # bias, weights, nb_inputs, kernel_size, nb_neurons, activation (nnet.h:75-82)
+            b, w, rw, dims, a = tok[0], tok[1], None, (int(tok[2]), int(tok[3]), int(tok[4])), tok[5]
+        else:                        # bias, weights, recurrent, nb_inputs, nb_neurons, activation, reset_after (nnet.h:62-70)
+            b, w, rw, dims, a = tok[0], tok[1], tok[2], (int(tok[3]), 1, int(tok[4])), tok[5]
+            if int(tok[6]) != 1:
+                raise ValueError(f"{name}: reset_after = {tok[6]}; only reset_after GRUs exist in this engine (dump_percepnet.py:94-98)")
+        if dims != (nin, ks, nn_):
+            raise ValueError(f"{name}: geometry {dims} is not the PercepNet topology's {(nin, ks, nn_)}")
+        acts[name] = _ACT_CODE[a.replace("ACTIVATION_", "")]
+        d = {"bias": arrays[b], "input_weights": arrays[w]}
+        if rw:
+            d["recurrent_weights"] = arrays[rw]
+        out[name] = d
+    return out, acts
+
+
+def export_main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m percepnet_amd.weights",
+                                 description="Convert a trained PercepNet (rnn_train.py checkpoint or the nnet_data.cpp text "
+                                             "dump_percepnet.py writes) into the PNW1 container libpercepnet_hip loads.")
+    src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument("--checkpoint", help="torch.save()d state_dict of rnn_train.PercepNet (rnn_train.py:245,322)")
+    src.add_argument("--nnet-data", help="C text written by dump_percepnet.py (src/nnet_data.cpp)")
+    src.add_argument("--seed", type=int, help="the seeded default-init network of BASELINE.md (no trained model exists upstream)")
+    ap.add_argument("-o", "--output", required=True)
+    a = ap.parse_args(argv)
+    acts = None
+    if a.checkpoint:
+        import torch
+        try:
+            sd = torch.load(a.checkpoint, map_location="cpu", weights_only=True)
+        except TypeError:
+            sd = torch.load(a.checkpoint, map_location="cpu")
+        layers = layers_from_state_dict(sd)
+    elif a.nnet_data:
+        layers, acts = layers_from_nnet_data(open(a.nnet_data).read())
+    else:
+        layers = modules_to_layers(build_torch_modules(a.seed))
+    blob = pack_blob(layers, acts)
+    with open(a.output, "wb") as f:
+        f.write(blob)
+    n = sum(v.size for d in layers.values() for v in d.values())
+    print(f"{a.output}: PNW1, {len(LAYERS)} layers, {n} parameters, {len(blob)} bytes, "
+          f"sha256 {hashlib.sha256(blob).hexdigest()[:16]}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(export_main())
