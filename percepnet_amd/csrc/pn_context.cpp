@@ -8,7 +8,10 @@
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "pn_launch.h"
@@ -163,12 +166,21 @@ struct pn_ctx {
   } pipe;
 };
 
+static thread_local bool g_last_alloc_oom = false;     // the last dev_alloc failure on this thread was hipErrorOutOfMemory
 static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
   // PERCEPNET_GUARD=1 (debugging aid): every buffer is followed by 1 MB of 0xFF (NaN as fp32 and as fp16), so that a
   // read past the end of a buffer shows up as NaN in the outputs instead of as run-to-run noise
   static const bool guard = getenv("PERCEPNET_GUARD") != NULL;
   const size_t pad = guard ? (1u << 20) : 0, body = (bytes + 255) & ~(size_t)255;
-  PN_HIP_CHECK(hipMalloc(p, guard ? body + pad : bytes));
+  {
+    const hipError_t e = hipMalloc(p, guard ? body + pad : bytes);
+    if (e != hipSuccess) {
+      g_last_alloc_oom = (e == hipErrorOutOfMemory);
+      (void)hipGetLastError();
+      pn_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return -1;
+    }
+  }
   c->allocs.push_back(*p);
   c->bytes += bytes;
   if (zero) PN_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, c->stream));
@@ -212,7 +224,9 @@ static int zero_state(pn_ctx *c) {
   return 0;
 }
 
-static int nn_selftest(pn_ctx *c, const pn_model *model);
+static int nn_selftest(pn_ctx *c);
+static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
+                          int force_small, int force_small_gru);
 
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
@@ -231,6 +245,13 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
 }
 
 extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream) {
+  return ctx_create(model, device, n_streams, nn_mode, hip_stream, true, -1, -1);
+}
+
+// force_small / force_small_gru: -1 = choose the network kernel family from the batch size (the public behaviour);
+// 0 / 1 = the self-test's temporary contexts run the SAME family as the context under test whatever their own size.
+static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
+                          int force_small, int force_small_gru) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
   if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
@@ -243,7 +264,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
   DeviceGuard _dg(device);
   if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = n_streams <= pn_small_rows(); c->small_gru = n_streams <= pn_small_gru_rows(); c->fe_g2 = getenv("PERCEPNET_FE_G2") ? atoi(getenv("PERCEPNET_FE_G2")) != 0 : n_streams <= 2048;   /* measured crossover: 0.125 vs 0.157 ms at 2048, 0.245 vs 0.168 at 4096 */ c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_g2 = getenv("PERCEPNET_FE_G2") ? atoi(getenv("PERCEPNET_FE_G2")) != 0 : n_streams <= 2048;   /* measured crossover: 0.125 vs 0.157 ms at 2048, 0.245 vs 0.168 at 4096 */ c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -328,7 +349,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
     }
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
-  if (nn_mode == PN_NN_MFMA && nn_selftest(c, model)) goto fail;
+  if (selftest && nn_mode != PN_NN_STRICT && nn_selftest(c)) goto fail;
   return c;
 fail:
   pn_ctx_destroy(c);
@@ -476,66 +497,88 @@ static void launch_rnn(pn_ctx *c) {
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B, c->small); }
 }
 
-// Known-answer self-test of the MFMA network kernels, run once per context creation (PERCEPNET_SELFTEST=0 skips it).
-// The MFMA path depends on hand-placed wait states and pinned instruction order; a toolchain that
-// schedules it differently could lose accumulator updates silently (the failure once seen hit output rows 27/31 mod
-// 32 only).  So the freshly built context runs two network steps on a fixed pseudo-random input over up to 192 rows
-// (six 32-row wave tiles, two M tiles) with the MFMA kernels and again with the reference-order STRICT kernels on
-// the same weights, and refuses to come up if any g/r output differs by more than the documented 2e-5.
-static int nn_selftest(pn_ctx *c, const pn_model *model) {
+// Known-answer self-test of the MFMA network kernels (PERCEPNET_SELFTEST=0 skips it).
+// The MFMA paths (fp32 and fp16 operands) depend on the compiler's wait-state insertion and on pinned instruction
+// order; a toolchain that schedules them differently could lose accumulator updates silently (the
+// failure once seen hit output rows 27/31 mod 32 only).  So the first context of every (device, nn_mode, kernel
+// family) in a process triggers one check of THE KERNELS — not of the caller's model: a fixed built-in synthetic weight
+// set (uniform +-1/sqrt(fan_in), LCG-generated, so the expected MFMA-vs-reference-order difference is a known ~1e-6) is
+// run for two network steps over 192 rows (six 32-row wave tiles, two M tiles) through two temporary contexts — the
+// kernel family under test and the reference-order STRICT kernels — and the context is refused if any g/r output
+// differs by more than the mode's documented tolerance (2e-5 fp32 operands, 1e-3 fp16).  The verdict is cached for
+// the process; a self-test that cannot allocate its ~70 MB of temporaries is reported as SKIPPED, not as a failure.
+static std::mutex g_selftest_mu;
+static std::map<std::tuple<int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
+
+static pn_model *selftest_model() {
+  static std::vector<float> store;
+  LayerSrc s[PN_NLAYERS];
+  size_t total = 0, nb, nw, nr;
+  for (int li = 0; li < PN_NLAYERS; li++) total += layer_floats(kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, &nb, &nw, &nr);
+  store.resize(total);
+  unsigned x = 2463534242u;
+  size_t off = 0;
+  static const int act[PN_NLAYERS] = {3, 3, 2, 2, 2, 2, 2, 2, 1, 1};        // relu relu tanh tanh*5 sigmoid sigmoid (rnn_train.py:105-121)
+  for (int li = 0; li < PN_NLAYERS; li++) {
+    layer_floats(kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, &nb, &nw, &nr);
+    const float bound_w = 1.f / sqrtf((float)(kGeom[li].kind == PN_KIND_GRU ? kGeom[li].nn : kGeom[li].nin * kGeom[li].ks));
+    for (size_t i = 0; i < nb + nw + nr; i++) {
+      x = x * 1664525u + 1013904223u;
+      store[off + i] = ((int)(x >> 8) % 20001 - 10000) * 1e-4f * bound_w;
+    }
+    s[li] = {kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, act[li], 1, &store[off], &store[off + nb], nr ? &store[off + nb + nw] : NULL};
+    off += nb + nw + nr;
+  }
+  pn_model *m = model_from_sources(s);
+  store.clear(); store.shrink_to_fit();
+  return m;
+}
+
+static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const int B_full = c->B, rows = B_full < 192 ? B_full : 192;
+  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru);
+  std::lock_guard<std::mutex> lk(g_selftest_mu);
+  if (g_selftest_done.count(key)) return 0;
+  const int rows = 192;
+  const float tol = c->nn_mode == PN_NN_MFMA_F16 ? 1e-3f : 2e-5f;
+  pn_model *m = selftest_model();
+  pn_ctx *cx[2] = {NULL, NULL};
   std::vector<float> feat((size_t)rows * PN_NFEAT), gr[2][2];
-  unsigned x = 12345u;
-  auto fill = [&]() { for (float &v : feat) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 8) % 2001 - 1000) * 1.5e-3f; } };
-  DevLayer saved[PN_NLAYERS]; memcpy(saved, c->L, sizeof(saved));
-  std::vector<void *> temps;
-  int rc = 0;
-  c->B = rows;
-  for (int pass = 0; pass < 2 && !rc; pass++) {        // pass 0: MFMA kernels; pass 1: STRICT kernels
-    if (pass == 1) {
-      c->nn_mode = PN_NN_STRICT;
-      for (int li = 0; li < PN_NLAYERS && !rc; li++) {
-        const PnLayerHost &H = model->L[li];
-        size_t nb, nw, nr; layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
-        void *w = NULL, *rw = NULL;
-        if (hipMalloc(&w, nw * 4) != hipSuccess || hipMemcpyAsync(w, H.w, nw * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1;
-        if (w) temps.push_back(w);
-        if (!rc && nr) { if (hipMalloc(&rw, nr * 4) != hipSuccess || hipMemcpyAsync(rw, H.rw, nr * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1; if (rw) temps.push_back(rw); }
-        c->L[li].w = (float *)w; c->L[li].rw = (float *)rw;
-      }
-    }
-    x = 12345u;
+  int rc = m ? 0 : -1;
+  bool oom = false;
+  for (int pass = 0; pass < 2 && !rc; pass++) {          // pass 0: the kernel family under test; pass 1: STRICT kernels
+    g_last_alloc_oom = false;
+    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru);
+    if (!cx[pass]) { rc = -1; oom = g_last_alloc_oom; break; }
+    unsigned x = 12345u;
     for (int step = 0; step < 2 && !rc; step++) {
-      fill();
+      for (float &v : feat) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 8) % 2001 - 1000) * 1.5e-3f; }
       gr[pass][step].resize((size_t)rows * 68);
-      if (hipMemcpy2DAsync(c->feat, PN_FEAT_STRIDE * 4, feat.data(), PN_NFEAT * 4, PN_NFEAT * 4, rows, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = -1; break; }
-      launch_rnn(c);
-      c->tn++;
-      if (hipMemcpyAsync(gr[pass][step].data(), c->gr, (size_t)rows * 68 * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-          hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = -1;
+      if (pn_ctx_compute_rnn_host(cx[pass], feat.data(), gr[pass][step].data())) rc = -1;
     }
-    c->B = B_full;                                      // zero_state clears the whole batch
-    if (zero_state(c) || hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
-    c->B = rows;
   }
-  c->B = B_full; c->nn_mode = PN_NN_MFMA; memcpy(c->L, saved, sizeof(saved));
-  for (void *p : temps) hipFree(p);
-  if (rc) { pn_set_error("network self-test could not run (HIP error)"); return -1; }
-  float worst = 0, spread = 0; int wrow = 0, wcol = 0;
+  pn_ctx_destroy(cx[0]); pn_ctx_destroy(cx[1]); pn_model_free(m);
+  if (rc && oom) {
+    fprintf(stderr, "percepnet_hip: network self-test SKIPPED on device %d (not enough free memory for its temporaries): %s\n", c->device, pn_last_error());
+    g_selftest_done[key] = 1;
+    return 0;
+  }
+  if (rc) { std::string why = pn_last_error(); pn_set_error("network self-test could not run: %s", why.c_str()); return -1; }
+  float worst = 0; int wrow = 0, wcol = 0;
   for (int step = 0; step < 2; step++)
     for (size_t i = 0; i < gr[0][step].size(); i++) {
       const float d = fabsf(gr[0][step][i] - gr[1][step][i]);
       if (!(d <= worst)) { worst = d; wrow = (int)(i / 68); wcol = (int)(i % 68); }     // NaN lands here too
-      spread = fmaxf(spread, fabsf(gr[1][step][i] - gr[1][step][i % 68]));
     }
-  if (!(worst <= 2e-5f)) {
-    pn_set_error("network self-test FAILED: MFMA kernels differ from the reference-order kernels by %g at row %d (row %% 32 = %d), "
-                 "output %d — the build's instruction schedule is not the validated one (DESIGN.md 4.3); refusing to run",
-                 (double)worst, wrow, wrow % 32, wcol);
+  if (!(worst <= tol)) {
+    pn_set_error("network self-test FAILED (nn_mode %d, dense=%s gru=%s): the MFMA kernels differ from the reference-order kernels by %g "
+                 "(> %g) at row %d (row %% 32 = %d), output %d on the built-in weight set — the build's instruction schedule is "
+                 "not the validated one (DESIGN.md 4.3); refusing to run", c->nn_mode, c->small ? "small" : "batch",
+                 c->small_gru ? "small" : "batch", (double)worst, (double)tol, wrow, wrow % 32, wcol);
     return -1;
   }
+  g_selftest_done[key] = 0;
   return 0;
 }
 

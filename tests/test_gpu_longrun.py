@@ -183,7 +183,7 @@ def test_configs2_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle)
 
 def test_fp16_variant_1000_frames_tolerance_holds(model, oracle):
     """configs[4] (fp16 GEMM operands, fp32 accumulate/state/DSP) over the same 10 s horizon: the re-stated tolerance
-    (PCM <= 4 LSB, g/r <= 1e-3) must hold for all 1000 frames — the recurrent state sees rounded
+    (PCM <= 6 LSB stated, 4 measured; g/r <= 1e-3) must hold for all 1000 frames — the recurrent state sees rounded
     operands every step, so this is where a slow drift would show — and the features, which never touch the
     network, stay bit-equal."""
     import torch
@@ -206,5 +206,5 @@ def test_fp16_variant_1000_frames_tolerance_holds(model, oracle):
         "max_abs_delta_gr": float(dg.max()), "mean_abs_delta_gr": float(dg.mean()),
         "max_abs_delta_gr_by_second": [float(dg[:, k:k + 100].max()) for k in range(0, T, 100)]})
     assert np.array_equal(feat.view(np.uint32), rf.view(np.uint32)) and np.array_equal(sil, rs)
-    assert d.max() <= 4, int(d.max())
+    assert d.max() <= 6, int(d.max())            # stated bound: 6 LSB (measured max 4; tests/test_gpu_stress_weights.py has the larger sample)
     assert dg.max() <= 1e-3, float(dg.max())
