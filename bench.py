@@ -504,13 +504,17 @@ def main():
         # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
         # are 0.2 s, shorter than the time the chip needs to settle on its power-limited clock.
         if world == 1 and not a.no_sustained and not a.strict:
-            n_sus = max(K, int(a.sustained_seconds / max(dt / K, 1e-6)) + 1)
+            n_sus, ds, per = 0, 0.0, max(dt / K, 1e-6)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n_sus):
-                ctx.process_i16_dev(frames[i % T].data_ptr(), out.data_ptr(), None)
-            torch.cuda.synchronize()
-            ds = time.perf_counter() - t0
+            while ds < a.sustained_seconds:                      # chunks sized from the rate seen so far; one sync per chunk
+                n = max(K, int((a.sustained_seconds - ds) / per * 1.05) + 1)
+                t0 = time.perf_counter()
+                for i in range(n):
+                    ctx.process_i16_dev(frames[(n_sus + i) % T].data_ptr(), out.data_ptr(), None)
+                torch.cuda.synchronize()
+                ds += time.perf_counter() - t0
+                n_sus += n
+                per = ds / n_sus
             res["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 4),
                                 "value": round(B * n_sus / ds / 100.0, 1), "unit": "streams",
                                 "sclk_mhz_at_end": gpu_clock_mhz(),
