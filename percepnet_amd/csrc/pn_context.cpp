@@ -123,15 +123,19 @@ extern "C" pn_model *pn_model_from_file(FILE *f) {
 extern "C" void pn_model_free(pn_model *m) { if (m) { free(m->storage); free(m); } }
 
 // ---- contexts -----------------------------------------------------------------------------------------
-enum { KF_FRONTEND, KF_FC, KF_CONV1, KF_CONV2, KF_GRU512, KF_GRU_RB, KF_FC_GB, KF_FC_RB, KF_BACKEND, KF_COUNT };
-static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2", "gru512", "gru_rb", "fc_gb", "fc_rb", "backend"};
+enum { KF_FRONTEND, KF_FC, KF_CONV1, KF_CONV2, KF_GRU512, KF_GRU_RB, KF_FC_GB, KF_FC_RB, KF_BACKEND, KF_FE_SPEC_IN, KF_FE_PITCH,
+       KF_FE_SPEC_OUT, KF_COUNT };
+static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2", "gru512", "gru_rb", "fc_gb", "fc_rb", "backend",
+                                            "fe_spec_in", "fe_pitch", "fe_spec_out"};
+enum { FE_MONO_G4 = 0, FE_MONO_G2 = 1, FE_SPLIT = 2 };
 
 struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
 
 struct pn_ctx {
   int device, B, nn_mode;
   int small, small_gru;            // network kernel family per layer kind: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
-  int fe_g2;                       // front end: 1 = two streams per wavefront (pn_dsp_fe_g2.hip), small batches only
+  int fe_mode;                     // front end: FE_SPLIT = three phase kernels (pn_dsp_fe_split_*.hip); FE_MONO_G4 / FE_MONO_G2 = the
+                                   // single-launch kernel with four / two streams per wavefront (pn_dsp_fe.hip, pn_dsp_fe_g2.hip)
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
   hipStream_t stream; bool own_stream;
   int64_t t;                       // frames done: indexes the DSP rings (hist slot t%12, yring/eyring t%6)
@@ -224,6 +228,17 @@ static int zero_state(pn_ctx *c) {
   return 0;
 }
 
+// Front-end kernel family for a batch size.  PERCEPNET_FE=split|mono|g2 overrides (PERCEPNET_FE_G2=1 is the older
+// spelling of g2).
+static int pn_fe_mode_for(int n_streams) {
+  if (const char *e = getenv("PERCEPNET_FE")) {
+    if (!strcmp(e, "split")) return FE_SPLIT;
+    if (!strcmp(e, "mono") || !strcmp(e, "g4")) return FE_MONO_G4;
+    if (!strcmp(e, "g2")) return FE_MONO_G2;
+  }
+  if (const char *e = getenv("PERCEPNET_FE_G2")) return atoi(e) ? FE_MONO_G2 : FE_MONO_G4;
+  return n_streams <= 2048 ? FE_MONO_G2 : FE_SPLIT;
+}
 static int nn_selftest(pn_ctx *c);
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
                           int force_small, int force_small_gru);
@@ -264,7 +279,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   DeviceGuard _dg(device);
   if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_g2 = getenv("PERCEPNET_FE_G2") ? atoi(getenv("PERCEPNET_FE_G2")) != 0 : n_streams <= 2048;   /* measured crossover: 0.125 vs 0.157 ms at 2048, 0.245 vs 0.168 at 4096 */ c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_mode = pn_fe_mode_for(n_streams); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -366,7 +381,7 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : "mfma_f32");
   const bool fam = c->nn_mode == PN_NN_MFMA;            // the small-batch family exists for the fp32 MFMA mode only
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
-                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch", c->fe_g2 ? "g2" : "g4");
+                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch", c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
   return (w < 0 || (size_t)w >= n) ? -1 : w;
 }
 extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
@@ -502,7 +517,8 @@ static void launch_rnn(pn_ctx *c) {
 // order; a toolchain that schedules them differently could lose accumulator updates silently (the
 // failure once seen hit output rows 27/31 mod 32 only).  So the first context of every (device, nn_mode, kernel
 // family) in a process triggers one check of THE KERNELS — not of the caller's model: a fixed built-in synthetic weight
-// set (uniform +-1/sqrt(fan_in), LCG-generated, so the expected MFMA-vs-reference-order difference is a known ~1e-6) is
+// set (uniform +-3/sqrt(fan_in), LCG-generated: gates from saturated to linear; the expected MFMA-vs-reference-order
+// difference over two steps from the zero state is known and small; PERCEPNET_SELFTEST=2 prints it) is
 // run for two network steps over 192 rows (six 32-row wave tiles, two M tiles) through two temporary contexts — the
 // kernel family under test and the reference-order STRICT kernels — and the context is refused if any g/r output
 // differs by more than the mode's documented tolerance (2e-5 fp32 operands, 1e-3 fp16).  The verdict is cached for
@@ -524,7 +540,9 @@ static pn_model *selftest_model() {
     const float bound_w = 1.f / sqrtf((float)(kGeom[li].kind == PN_KIND_GRU ? kGeom[li].nn : kGeom[li].nin * kGeom[li].ks));
     for (size_t i = 0; i < nb + nw + nr; i++) {
       x = x * 1664525u + 1013904223u;
-      store[off + i] = ((int)(x >> 8) % 20001 - 10000) * 1e-4f * bound_w;
+      // x3: a good share of the GRU gates and tanh outputs saturate, so the clamped end of the activation table
+      // (indices 192..200: a 192-thread block once failed to stage them) is exercised, not only its linear middle
+      store[off + i] = ((int)(x >> 8) % 20001 - 10000) * 1e-4f * bound_w * (i < nb ? 1.f : 3.f);
     }
     s[li] = {kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, act[li], 1, &store[off], &store[off + nb], nr ? &store[off + nb + nw] : NULL};
     off += nb + nw + nr;
@@ -571,6 +589,9 @@ static int nn_selftest(pn_ctx *c) {
       const float d = fabsf(gr[0][step][i] - gr[1][step][i]);
       if (!(d <= worst)) { worst = d; wrow = (int)(i / 68); wcol = (int)(i % 68); }     // NaN lands here too
     }
+  if (env && atoi(env) >= 2)
+    fprintf(stderr, "percepnet_hip: network self-test device %d nn_mode %d dense=%s gru=%s: worst |delta g,r| %g (tolerance %g) at row %d output %d\n",
+            c->device, c->nn_mode, c->small ? "small" : "batch", c->small_gru ? "small" : "batch", (double)worst, (double)tol, wrow, wcol);
   if (!(worst <= tol)) {
     pn_set_error("network self-test FAILED (nn_mode %d, dense=%s gru=%s): the MFMA kernels differ from the reference-order kernels by %g "
                  "(> %g) at row %d (row %% 32 = %d), output %d on the built-in weight set — the build's instruction schedule is "
@@ -585,9 +606,19 @@ static int nn_selftest(pn_ctx *c) {
 static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16) {
   if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
   PN_ON_DEVICE(c);
-  { Scope sc(c, KF_FRONTEND);
-    (c->fe_g2 ? pn_launch_frontend_g2 : pn_launch_frontend)(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f,
-        c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr); }
+  if (c->fe_mode == FE_SPLIT) {
+    { Scope sc(c, KF_FE_SPEC_IN);
+      pn_launch_fe_spec_in(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring, c->eyring); }
+    { Scope sc(c, KF_FE_PITCH);
+      pn_launch_fe_pitch(c->stream, c->B, c->t, c->hist, c->feat, c->last_period, c->last_gain, nullptr); }
+    { Scope sc(c, KF_FE_SPEC_OUT);
+      pn_launch_fe_spec_out(c->stream, c->tables, c->B, c->t, c->hist, c->yring, c->eyring, c->last_period, c->Ps, c->feat,
+                            c->silence, nullptr); }
+  } else {
+    Scope sc(c, KF_FRONTEND);
+    (c->fe_mode == FE_MONO_G2 ? pn_launch_frontend_g2 : pn_launch_frontend)(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f,
+        c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr);
+  }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
     // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6

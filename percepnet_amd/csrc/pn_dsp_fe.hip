@@ -32,49 +32,8 @@
 // per CU (146 KB LDS), grid-stride over stream quartets.  No block barrier after the staging:
 // groups never exchange data, LDS operations of one wave execute in order, PN_WAVE_SYNC is a
 // compiler fence.
-#include "pn_common.h"
+#include "pn_dsp_fe_helpers.inc"
 
-#define LANES 64
-#ifndef PN_FE_G
-#define PN_FE_G 4               // streams per wave (4 or 2)
-#endif
-#define G PN_FE_G
-#define L (LANES / G)           // lanes per stream
-#ifndef PN_FE_SPB
-#define PN_FE_SPB 16            // streams per block: 16 = 146 KB LDS, one block per CU; 8 = 80 KB (can share a CU with a GEMM block)
-#endif
-#define FE_WPB (PN_FE_SPB / G)  // waves per block
-#define NCH ((147 + L - 1) / L) // coarse-search lags per lane
-#define NBND ((PN_NB + L - 1) / L)
-// Band -> (lane, slot) assignment of the band reductions.  The lanes of a group run slot c in lock-step, so a slot costs
-// as much as its widest band (ERB bands grow from 2 to 96 bins): slot 0 takes the 16 widest bands, slot 1 the next 16,
-// slot 2 the rest -> 13 + 2 + 2 eight-bin steps instead of 1 + 11 + 13 with the natural b = l + 16 c.  Any permutation
-// is correct; this one is tuned for the 34-band table of erbband.h.
-#if PN_FE_G == 4
-__device__ const uint8_t kFeBandMap[16][4] = {
-    {32, 2, 18, 34}, {31, 3, 0, 34},  {30, 4, 34, 34},  {29, 5, 34, 34},  {28, 6, 34, 34},  {27, 7, 34, 34},
-    {33, 8, 34, 34}, {25, 9, 34, 34}, {26, 10, 34, 34}, {24, 11, 34, 34}, {20, 12, 34, 34}, {21, 13, 34, 34},
-    {22, 14, 34, 34}, {23, 15, 34, 34}, {19, 16, 34, 34}, {1, 17, 34, 34}};
-#define FE_BAND_OF(S_, l_, c_) ((int)(S_).bmap[(l_) * 4 + (c_)])
-#else
-#define FE_BAND_OF(S_, l_, c_) ((l_) + L * (c_))
-#endif
-#define FE_THREADS (LANES * FE_WPB)
-#define FE_SPB (FE_WPB * G)     // streams per block
-
-#define PN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define PN_WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
-
-struct alignas(16) FeTablesLds {
-  float2 tw[PN_NFFT];            // 7680 B
-  float win[PN_FRAME];           // 1920 B
-  float frac[PN_SPEC_BINS];      // 1600 B
-  int16_t bitrev[PN_NFFT];       // 1920 B
-  int16_t border[PN_NB + 2];
-  uint8_t band[PN_SPEC_BINS];
-  uint8_t bmap[64];              // band handled by (lane l, slot c) at [l * 4 + c]; 34 = none
-  float comb_w[8];
-};
 struct alignas(16) FeStreamLds {
   float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
   float e[4][PN_NB + 2];         // 576 B
@@ -93,345 +52,6 @@ struct FeShared {
 #define OFF_PBUF 864     // [864,1728) whitened decimated signal  (pitch_buf>>1)
 #define OFF_D1 1728      // [1728,1876) d[] of the coarse pass (148)
 #define OFF_PROD 960     // [960,1360) per-bin X.P products (after the P FFT; bins live in [0,800))
-
-#define CMUL(m, a, b) do { (m).x = (a).x*(b).x - (a).y*(b).y; (m).y = (a).x*(b).y + (a).y*(b).x; } while (0)
-
-// ---- 960-point FFT in LDS by L lanes (opus_fft_impl, kiss_fft.cpp:518-564, factors 5,3,4,4,4);
-// input already scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585) --------------------
-__device__ __forceinline__ void fe_fft960(float2 *F, const float2 *tw, int l) {
-  PN_WAVE_SYNC();
-#pragma unroll 5
-  for (int b = l; b < 240; b += L) {        // radix-4, m=1 (kiss_fft.cpp:112-131)
-    float2 *f = F + 4 * b;
-    float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
-    s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
-    f0.x += f2.x; f0.y += f2.y;
-    s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
-    f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
-    f0.x += s1.x; f0.y += s1.y;
-    s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
-    f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
-    f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
-    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
-  }
-  PN_WAVE_SYNC();
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {    // radix-4, m=4 (fstride 60) then m=16 (fstride 15) (139-166)
-    const int m = pass ? 16 : 4, fs = pass ? 15 : 60, mm = pass ? 64 : 16;
-#pragma unroll 5
-    for (int b = l; b < 240; b += L) {
-      const int i = b / m, j = b % m;
-      float2 *f = F + i * mm + j;
-      float2 f0 = f[0], fm = f[m], f2m = f[2 * m], f3m = f[3 * m];
-      const float2 t1 = tw[j * fs], t2 = tw[2 * j * fs], t3 = tw[3 * j * fs];
-      float2 s0, s1, s2, s3, s4, s5;
-      CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
-      s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
-      f0.x += s1.x; f0.y += s1.y;
-      s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
-      s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
-      f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
-      f0.x += s3.x; f0.y += s3.y;
-      fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
-      f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
-      f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
-    }
-    PN_WAVE_SYNC();
-  }
-  {
-    const float epi3 = tw[320].y;           // radix-3, m=64, fstride 5 (196-227)
-#pragma unroll 5
-    for (int b = l; b < 320; b += L) {
-      const int i = b >> 6, j = b & 63;
-      float2 *f = F + i * 192 + j;
-      float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
-      CMUL(s1, fm, tw[j * 5]); CMUL(s2, f2m, tw[2 * j * 5]);
-      s3.x = s1.x + s2.x; s3.y = s1.y + s2.y;
-      s0.x = s1.x - s2.x; s0.y = s1.y - s2.y;
-      fm.x = f0.x - s3.x * .5f; fm.y = f0.y - s3.y * .5f;
-      s0.x *= epi3; s0.y *= epi3;
-      f0.x += s3.x; f0.y += s3.y;
-      f2m.x = fm.x + s0.y; f2m.y = fm.y - s0.x;
-      fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
-      f[0] = f0; f[64] = fm; f[128] = f2m;
-    }
-    PN_WAVE_SYNC();
-  }
-  {
-    const float2 ya = tw[192], yb = tw[384]; // radix-5, m=192, fstride 1 (259-304)
-#pragma unroll 4
-    for (int u = l; u < 192; u += L) {
-      float2 *f = F + u;
-      float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
-      float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
-      CMUL(s1, f1, tw[u]); CMUL(s2, f2, tw[2 * u]); CMUL(s3, f3, tw[3 * u]); CMUL(s4, f4, tw[4 * u]);
-      s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
-      s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
-      s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
-      s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
-      f0.x = f0.x + (s7.x + s8.x);
-      f0.y = f0.y + (s7.y + s8.y);
-      s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
-      s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
-      s6.x = s10.y * ya.y + s9.y * yb.y;
-      s6.y = -(s10.x * ya.y + s9.x * yb.y);
-      f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
-      f4.x = s5.x + s6.x; f4.y = s5.y + s6.y;
-      s11.x = s0.x + (s7.x * yb.x + s8.x * ya.x);
-      s11.y = s0.y + (s7.y * yb.x + s8.y * ya.x);
-      s12.x = s9.y * ya.y - s10.y * yb.y;
-      s12.y = s10.x * yb.y - s9.x * ya.y;
-      f2.x = s11.x + s12.x; f2.y = s11.y + s12.y;
-      f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
-      f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
-    }
-    PN_WAVE_SYNC();
-  }
-}
-
-// ---- band reductions (denoise.cpp:89-160): the lane owning band b sums in the reference's order.
-// PROD=false: tmp = |A[k]|^2 (compute_band_energy); PROD=true: tmp[k] precomputed (compute_band_corr).
-template <bool PROD>
-__device__ __forceinline__ float fe_band(const FeTablesLds &T, const float2 *A, const float *prod, int b) {
-  float sum = 0;
-  const bool valid = b < PN_NB;
-  const int bb = valid ? b : 0;
-  // interval i = b-1 contributes `sum[i+1] += frac*tmp`, interval i = b `sum[i] += (1-frac)*tmp`,
-  // each j ascending (denoise.cpp:97-104).  Operands are fetched 8 bins ahead of the add chain.
-#pragma unroll
-  for (int part = 0; part < 2; part++) {
-    const bool on = valid && (part == 0 ? bb >= 1 : bb <= PN_NB - 2);
-    const int lo = on ? T.border[part == 0 ? bb - 1 : bb] : 0;
-    const int hi = on ? T.border[part == 0 ? bb : bb + 1] : 0;
-    for (int k0 = lo; k0 < hi; k0 += 8) {
-      float tv[8], fv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int k = (k0 + u < hi) ? k0 + u : hi - 1;
-        if (PROD) tv[u] = prod[k];
-        else { const float2 a = A[k]; float t = a.x * a.x; t += a.y * a.y; tv[u] = t; }
-        fv[u] = T.frac[k];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (k0 + u < hi) sum += (part == 0 ? fv[u] : (1 - fv[u])) * tv[u];
-    }
-  }
-  if (valid && (b == 0 || b == PN_NB - 1)) sum *= 2;
-  return sum;
-}
-
-// logical comb_buf index j in [0,5760) (newest sample at 5759) -> ring offset: (j + 480*base_slot) mod 5760
-__device__ __forceinline__ int fe_ring(int j, int base_slot) {
-  const int p = j + base_slot * PN_FRAME;
-  return p >= PN_HIST ? p - PN_HIST : p;
-}
-typedef float fe_f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 consecutive samples at any dword alignment
-
-// acc + sum_{j<N} a[j]*b[j], adds strictly in j order (celt_inner_prod / xcorr_kernel, pitch.h:53-144).
-// `a` is uniform within the group: ds_read_b128 at one address (16-byte aligned); b is per lane.
-// Two register sets: the LDS reads of block k+1 are in flight while the (serially dependent) adds
-// of block k execute.
-#define FE_CH_LOAD(av, bv, blk) do {                                                                   \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
-    _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) (bv)[u_] = b[16 * (blk) + u_];                   \
-  } while (0)
-#define FE_CH_MAC(av, bv) do {                                                                         \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                                 \
-      acc = acc + (av)[v_].x * (bv)[4 * v_]; acc = acc + (av)[v_].y * (bv)[4 * v_ + 1];                \
-      acc = acc + (av)[v_].z * (bv)[4 * v_ + 2]; acc = acc + (av)[v_].w * (bv)[4 * v_ + 3];            \
-    }                                                                                                  \
-  } while (0)
-template <int N>
-__device__ __forceinline__ float fe_chain(const float *a, const float *b, float acc) {
-  constexpr int U = 16, NF = N / U, R = N % U;
-  float4 a0[4], a1[4]; float b0[U], b1[U];
-  FE_CH_LOAD(a0, b0, 0);
-#pragma unroll 1
-  for (int blk = 0; blk < NF; blk += 2) {
-    if (blk + 1 < NF) FE_CH_LOAD(a1, b1, blk + 1);
-    FE_CH_MAC(a0, b0);
-    if (blk + 2 < NF) FE_CH_LOAD(a0, b0, blk + 2);
-    if (blk + 1 < NF) FE_CH_MAC(a1, b1);
-  }
-  if (R) {
-    float4 av[R / 4 ? R / 4 : 1]; float bv[R ? R : 1];
-#pragma unroll
-    for (int v = 0; v < R / 4; v++) av[v] = *reinterpret_cast<const float4 *>(a + U * NF + 4 * v);
-#pragma unroll
-    for (int u = 0; u < R; u++) bv[u] = b[U * NF + u];
-#pragma unroll
-    for (int v = 0; v < R / 4; v++) {
-      acc = acc + av[v].x * bv[4 * v]; acc = acc + av[v].y * bv[4 * v + 1];
-      acc = acc + av[v].z * bv[4 * v + 2]; acc = acc + av[v].w * bv[4 * v + 3];
-    }
-  }
-  return acc;
-}
-#undef FE_CH_LOAD
-#undef FE_CH_MAC
-// two chains sharing the uniform operand: acc1 += a.b1, acc2 += a.b2
-#define FE_CH2_LOAD(av, v1, v2, blk) do {                                                              \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
-    _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) { (v1)[u_] = b1[16 * (blk) + u_]; (v2)[u_] = b2[16 * (blk) + u_]; } \
-  } while (0)
-#define FE_CH2_MAC(av, v1, v2) do {                                                                    \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                                 \
-      acc1 = acc1 + (av)[v_].x * (v1)[4 * v_]; acc2 = acc2 + (av)[v_].x * (v2)[4 * v_];                \
-      acc1 = acc1 + (av)[v_].y * (v1)[4 * v_ + 1]; acc2 = acc2 + (av)[v_].y * (v2)[4 * v_ + 1];        \
-      acc1 = acc1 + (av)[v_].z * (v1)[4 * v_ + 2]; acc2 = acc2 + (av)[v_].z * (v2)[4 * v_ + 2];        \
-      acc1 = acc1 + (av)[v_].w * (v1)[4 * v_ + 3]; acc2 = acc2 + (av)[v_].w * (v2)[4 * v_ + 3];        \
-    }                                                                                                  \
-  } while (0)
-template <int N>
-__device__ __forceinline__ void fe_chain2(const float *a, const float *b1, const float *b2, float &acc1, float &acc2) {
-  constexpr int U = 16, NF = N / U;
-  static_assert(N % U == 0 && NF % 2 == 0, "N");
-  float4 a0[4], a1[4]; float p0[U], q0[U], p1[U], q1[U];
-  FE_CH2_LOAD(a0, p0, q0, 0);
-#pragma unroll 1
-  for (int blk = 0; blk < NF; blk += 2) {
-    FE_CH2_LOAD(a1, p1, q1, blk + 1);
-    FE_CH2_MAC(a0, p0, q0);
-    if (blk + 2 < NF) FE_CH2_LOAD(a0, p0, q0, blk + 2);
-    FE_CH2_MAC(a1, p1, q1);
-  }
-}
-#undef FE_CH2_LOAD
-#undef FE_CH2_MAC
-
-// find_best_pitch (pitch.cpp:46-104, float instantiation).  Group-uniform recurrence on broadcast
-// operands.  Everything that is not order-dependent is formed lane-parallel first with the reference's
-// roundings: the squares y[j]^2 for the initial energy (64 at a time into sq), the window updates
-// d[i] = y[i+LEN]^2 - y[i]^2, and the numerators num[i] = (xcorr[i]*1e-12)^2, with NaN standing for
-// "xcorr[i] <= 0: candidate skipped" (every comparison against NaN is false).  The serial part is then the
-// running-energy add + clamp per candidate and, only when some candidate of a group of four beats the current
-// second best, the cross-multiplied comparisons and selects on the (best, second best) state.  Every LDS
-// operand of a 64-candidate block is read before the serial chain starts (a read waited for inside the chain
-// costs its full ~120-cycle latency per four steps).  xcorr, d, sq 16-byte aligned; sq holds 64 floats.
-// sum NV4 float4 groups of sq into the serial energy chain: all LDS reads are issued before the first add
-template <int NV4>
-__device__ __forceinline__ float fe_sum_sq(const float *sq, float Syy) {
-  float4 q[NV4];
-#pragma unroll
-  for (int v = 0; v < NV4; v++) q[v] = *reinterpret_cast<const float4 *>(sq + 4 * v);
-#pragma unroll
-  for (int v = 0; v < NV4; v++) { Syy = Syy + q[v].x; Syy = Syy + q[v].y; Syy = Syy + q[v].z; Syy = Syy + q[v].w; }
-  return Syy;
-}
-
-// One candidate against the (best, second best) state; sy_ = running energy at that candidate.
-#define FE_FBP_STEP(nm_, sy_, idx_) do {                                                            \
-    const float num = (nm_);                                                                        \
-    const bool c1 = num * bd1 > bn1 * (sy_);                                                        \
-    const bool c0 = c1 && (num * bd0 > bn0 * (sy_));                                                \
-    bn1 = c0 ? bn0 : (c1 ? num : bn1); bd1 = c0 ? bd0 : (c1 ? (sy_) : bd1); bp1 = c0 ? bp0 : (c1 ? (idx_) : bp1); \
-    bn0 = c0 ? num : bn0; bd0 = c0 ? (sy_) : bd0; bp0 = c0 ? (idx_) : bp0;                          \
-  } while (0)
-#define FE_SYY_NEXT(sy_, dd_) ((1 > ((sy_) + (dd_))) ? 1 : ((sy_) + (dd_)))
-struct FeBest { float bn0, bn1, bd0, bd1; int bp0, bp1; };
-
-// NV4 groups of four candidates starting at candidate i0: operands read from LDS up front (8 groups at a time).
-// Four candidates at a time: the running energies do not depend on the search state, and a candidate changes
-// the state only if it beats the current second best — if none of the four does (in any of the wave's streams)
-// the state is the same before and after them and the selects are skipped.
-template <int NV4>
-__device__ __forceinline__ void fe_scan_groups(const float *nm, const float *d, int i0, float &Syy, FeBest &B) {
-  float bn0 = B.bn0, bn1 = B.bn1, bd0 = B.bd0, bd1 = B.bd1; int bp0 = B.bp0, bp1 = B.bp1;
-#pragma unroll
-  for (int h0 = 0; h0 < NV4; h0 += 8) {
-    constexpr int dummy = 0; (void)dummy;
-    float4 n4[8], d4[8];
-#pragma unroll
-    for (int v = 0; v < 8; v++) if (h0 + v < NV4) {
-      n4[v] = *reinterpret_cast<const float4 *>(nm + 4 * (h0 + v));
-      d4[v] = *reinterpret_cast<const float4 *>(d + 4 * (h0 + v));
-    }
-#pragma unroll
-    for (int v = 0; v < 8; v++) if (h0 + v < NV4) {
-      const int i = i0 + 4 * (h0 + v);
-      const float s0 = Syy, s1 = FE_SYY_NEXT(s0, d4[v].x), s2 = FE_SYY_NEXT(s1, d4[v].y), s3 = FE_SYY_NEXT(s2, d4[v].z);
-      Syy = FE_SYY_NEXT(s3, d4[v].w);
-      const bool any = (n4[v].x * bd1 > bn1 * s0) | (n4[v].y * bd1 > bn1 * s1) | (n4[v].z * bd1 > bn1 * s2) |
-                       (n4[v].w * bd1 > bn1 * s3);          // bitwise: no short-circuit branches
-      if (__ballot(any)) {
-        FE_FBP_STEP(n4[v].x, s0, i); FE_FBP_STEP(n4[v].y, s1, i + 1);
-        FE_FBP_STEP(n4[v].z, s2, i + 2); FE_FBP_STEP(n4[v].w, s3, i + 3);
-      }
-    }
-  }
-  B.bn0 = bn0; B.bn1 = bn1; B.bd0 = bd0; B.bd1 = bd1; B.bp0 = bp0; B.bp1 = bp1;
-}
-
-template <int LEN, int MAXP>
-__device__ __forceinline__ void fe_find_best_pitch(const float *xcorr, const float *y, float *sq, float *d, int l,
-                                                   int &bp0_out, int &bp1_out) {
-  constexpr int MP4 = (MAXP + 3) & ~3;
-  static_assert(LEN % 4 == 0, "LEN");
-  for (int i = l; i < MP4; i += L) {
-    const int ic = i < MAXP ? i : MAXP - 1;
-    const float a = y[ic + LEN], c = y[ic];
-    d[i] = a * a - c * c;
-  }
-  // initial energy Syy = 1 + sum_{j<LEN} y[j]^2, j ascending (pitch.cpp:62-63); squares lane-parallel 64 at a time
-  float Syy = 1.0f;
-  constexpr int FULL_Y = LEN / 64, TAIL_Y = (LEN % 64) / 4;
-#pragma unroll 1
-  for (int blk = 0; blk < FULL_Y + (TAIL_Y ? 1 : 0); blk++) {
-    float yv[64 / L];
-#pragma unroll
-    for (int w = 0; w < 64 / L; w++) { const int j = 64 * blk + l + L * w; yv[w] = y[j < LEN ? j : 0]; }
-    PN_WAVE_SYNC();
-#pragma unroll
-    for (int w = 0; w < 64 / L; w++) sq[l + L * w] = yv[w] * yv[w];
-    PN_WAVE_SYNC();
-    if (blk < FULL_Y) Syy = fe_sum_sq<16>(sq, Syy);
-    else Syy = fe_sum_sq<TAIL_Y ? TAIL_Y : 1>(sq, Syy);
-  }
-  FeBest B = {-1.f, -1.f, 0.f, 0.f, 0, 1};
-  constexpr int FULL_C = MP4 / 64, TAIL_C = (MP4 % 64) / 4;
-#pragma unroll 1
-  for (int blk = 0; blk < FULL_C + (TAIL_C ? 1 : 0); blk++) {
-    float nv[64 / L], xcv[64 / L];
-#pragma unroll
-    for (int w = 0; w < 64 / L; w++) { const int i = 64 * blk + l + L * w; xcv[w] = xcorr[i < MAXP ? i : 0]; }
-#pragma unroll
-    for (int w = 0; w < 64 / L; w++) {
-      const int i = 64 * blk + l + L * w;
-      const float xc = xcv[w];
-      float x16 = xc;
-      x16 *= 1e-12f;
-      nv[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");   // NaN: skipped (every comparison false)
-    }
-    PN_WAVE_SYNC();
-#pragma unroll
-    for (int w = 0; w < 64 / L; w++) sq[l + L * w] = nv[w];
-    PN_WAVE_SYNC();
-    if (blk < FULL_C) fe_scan_groups<16>(sq, d + 64 * blk, 64 * blk, Syy, B);
-    else fe_scan_groups<TAIL_C ? TAIL_C : 1>(sq, d + 64 * blk, 64 * blk, Syy, B);
-  }
-  bp0_out = B.bp0; bp1_out = B.bp1;
-}
-#undef FE_SYY_NEXT
-#undef FE_FBP_STEP
-
-// Tuning aid (variant builds with -DPN_FE_CLOCKS only): wave 0 of every block accumulates the shader-clock
-// cycles between phase marks into pn_fe_clk[]; read back with pn_fe_clocks_read().
-#ifdef PN_FE_CLOCKS
-#define FE_NMARK 24
-__device__ unsigned long long pn_fe_clk[FE_NMARK];
-#define FE_MARK(i) do { const long long now_ = __builtin_readcyclecounter(); \
-    if (tid == 0) atomicAdd(&pn_fe_clk[i], (unsigned long long)(now_ - tmark_)); tmark_ = __builtin_readcyclecounter(); } while (0)
-extern "C" int pn_fe_clocks_read(unsigned long long *out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_fe_clk), sizeof(unsigned long long) * FE_NMARK) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[FE_NMARK] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pn_fe_clk), z, sizeof(z)) != hipSuccess) return -1; }
-  return FE_NMARK;
-}
-#else
-#define FE_MARK(i) do {} while (0)
-#endif
-
-__device__ __forceinline__ float fe_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
 
 template <typename TIn>
 #ifndef PN_FE_WAVES_PER_SIMD

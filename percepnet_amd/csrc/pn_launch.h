@@ -14,6 +14,16 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_
 void pn_launch_frontend_g2(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
                            int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
                            float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+// the phase-split front end (pn_dsp_fe_split_s.hip, pn_dsp_fe_split_p.hip): three launches with their own lane mapping
+// and register / LDS budget; spec_in and pitch are independent of each other, spec_out needs both.  Same results, bit
+// for bit, as pn_launch_frontend.
+void pn_launch_fe_spec_in(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
+                          long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring);
+void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const float *hist, float *feat, int *last_period,
+                        float *last_gain, float *aux);
+void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const float *hist,
+                           const float2 *yring, const float *eyring, const int *last_period, float2 *Ps, float *feat,
+                           int *silence, float *aux);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,

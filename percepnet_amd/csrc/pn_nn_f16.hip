@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_f16_kernel(
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = mt * BM;
-  if (tid < 201) S.tansig[tid] = tansig[tid];
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];   // 201 entries whatever the block size (a 192-thread block once left 192..200 unstaged)
   floatx16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_f16_kernel(
   const int m0 = mt * BM, KTh = N / HK;
   const int T1 = KTx, TT = KTx + KTh;
   const int col = nt * 32 + (lane & 31);
-  if (tid < 201) S.tansig[tid] = tansig[tid];
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];   // 201 entries whatever the block size (a 192-thread block once left 192..200 unstaged)
   floatx16 acc[4];
   {
     float bz = b[col]; bz += b[3 * N + col];

