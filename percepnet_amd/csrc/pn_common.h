@@ -33,7 +33,15 @@ struct PnTables {
   int16_t bitrev[PN_NFFT];        // digit-reversal scatter index kiss_fft.cpp:315-345
   int16_t border[PN_NB + 2];      // ERBBand::nfftborder erbband.h:63-75
   uint8_t bin_band[PN_SPEC_BINS]; // band i with border[i] <= bin < border[i+1]
+  // Band-major operand layout of the phase-split front end's band reductions (pn_dsp_fe_split_s.hip): band b's chain
+  // reads, in order, frac*tmp of interval b-1 then (1-frac)*tmp of interval b; its operands are stored contiguously
+  // from float band_start[b] (a multiple of 4), each part padded with zeros to a multiple of 4, band_nq[b] quads in all.
+  uint16_t band_pos_a[PN_SPEC_BINS]; // where frac*tmp of bin k goes (band bin_band[k]+1, part 1)
+  uint16_t band_pos_b[PN_SPEC_BINS]; // where (1-frac)*tmp of bin k goes (band bin_band[k], part 2)
+  uint16_t band_start[PN_NB + 2];
+  uint16_t band_nq[PN_NB + 2];
 };
+#define PN_BAND_LAYOUT_FLOATS 920   // total size of that layout for the 34-band table of erbband.h (checked in pn_build_tables)
 
 void pn_build_tables(PnTables *t);
 

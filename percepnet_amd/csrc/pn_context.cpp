@@ -521,7 +521,7 @@ static void launch_rnn(pn_ctx *c) {
 // difference over two steps from the zero state is known and small; PERCEPNET_SELFTEST=2 prints it) is
 // run for two network steps over 192 rows (six 32-row wave tiles, two M tiles) through two temporary contexts — the
 // kernel family under test and the reference-order STRICT kernels — and the context is refused if any g/r output
-// differs by more than the mode's documented tolerance (2e-5 fp32 operands, 1e-3 fp16).  The verdict is cached for
+// differs by more than 2e-5 (fp32 operands) / 4e-3 (fp16 operands, whose rounding the x3 weights amplify).  The verdict is cached for
 // the process; a self-test that cannot allocate its ~70 MB of temporaries is reported as SKIPPED, not as a failure.
 static std::mutex g_selftest_mu;
 static std::map<std::tuple<int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
@@ -559,7 +559,7 @@ static int nn_selftest(pn_ctx *c) {
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
   const int rows = 192;
-  const float tol = c->nn_mode == PN_NN_MFMA_F16 ? 1e-3f : 2e-5f;
+  const float tol = c->nn_mode == PN_NN_MFMA_F16 ? 4e-3f : 2e-5f;    // measured on the built-in set: 8.3e-7 (fp32), 1.03e-3 (fp16 operands); a lost k-step is O(0.1)
   pn_model *m = selftest_model();
   pn_ctx *cx[2] = {NULL, NULL};
   std::vector<float> feat((size_t)rows * PN_NFEAT), gr[2][2];

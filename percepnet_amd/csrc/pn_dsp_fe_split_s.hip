@@ -1,4 +1,4 @@
-// Phase-split front end, spectral kernels (gfx950): ONE stream per wavefront, 64 lanes.
+// Phase-split front end, spectral kernels (gfx950): ONE stream per wavefront, 64 lanes, four waves per SIMD.
 //
 //   pn_fe_spec_in_kernel   history ring write, window + 960-pt FFT of the newest 960 samples -> look-ahead spectrum Y
 //                          and band energies Ey into their 6-slot rings (== the analysis side of frame_analysis for
@@ -6,302 +6,414 @@
 //   pn_fe_spec_out_kernel  7-tap comb filter at the pitch period the pitch kernel found, window + FFT -> P, Ep, the
 //                          X.P band correlation, the 68 band features, silence flag
 //                          (denoise.cpp:416-434, create_features 487-496)
-// The pitch analysis between the two lives in pn_dsp_fe_split_p.hip (four streams per wave).  Why three kernels: the
-// single-launch front end (pn_dsp_fe.hip) needs 8.3 KB of LDS per stream for its FFT buffer and 475 registers per lane
-// for the batched loads that hide latency with ONE wave per SIMD; its data-parallel phases (FFT, windows, comb filter)
-// have no use for four streams per wave.  Here they run with one stream per wave and FOUR waves per SIMD (<= 128
-// registers, 36.6 KB of LDS per 4-wave block, four blocks per CU): measured on MI355X, every instruction a lone wave
-// issues costs 4.5 cycles whatever its kind, two waves per SIMD double the rate and four reach the VALU peak
-// (profiles/r03a_valu_issue_probe.log).
+// The pitch analysis between the two lives in pn_dsp_fe_split_p.hip (four streams per wave).
+//
+// Why this shape.  Measured on MI355X (profiles/r03a_valu_issue_probe.log, r03c PMC): a lone wave issues one instruction
+// per 4.5 cycles whatever its kind, two waves per SIMD double that and four reach the VALU peak — so the data-parallel
+// phases want one stream per wave and four waves per SIMD (<= 128 registers, 8 KB of LDS per stream) — and from there the
+// CU-wide LDS pipe is what limits (first split version: 54 % of its LDS cycles were bank conflicts, 2.6 k LDS cycles
+// per stream-FFT-and-bands).  Hence:
+//   * the 960-point FFT runs as THREE register-fused passes instead of five in-place stages:
+//       P1  lane l < 60 holds window samples 4l+c+240k (four float4 straight from HBM): window, scale and the first
+//           radix-4 stage (kiss_fft.cpp:112-131) happen in registers; there is no digit-reversal scatter
+//       P2  lane l < 60: radix-4 stages m=4 and m=16 (139-166) on the 16 elements 64*blk + 16a + 4a' + j', in place
+//       P3  lane u < 64: radix-3 (196-227) and radix-5 (259-304) on the 15 elements u + 64b + 192c; the results stay
+//           in registers (bins >= 400 are never used, denoise.cpp:89-182: their butterflies' outputs are not formed)
+//     with the LDS layout phi(i) = i + 4*(i >> 6) (float2 units) that makes the P2 and P3 accesses bank-conflict-free;
+//     tools/fft960_model.py proves bit for bit that the three passes equal the five stages and prints the conflict
+//     factors;
+//   * the band reductions read their operands band-major (PnTables.band_*): the per-bin terms frac*tmp / (1-frac)*tmp
+//     are formed lane-parallel and stored where the band that sums them reads them as aligned float4 — one
+//     ds_read_b128 per four chain steps instead of two scalar reads per step.
 //
 // Numerics contract: as pn_dsp_fe.hip — every arithmetic step is the reference's operation in the reference's order
 // with separate IEEE binary32 rounding (-ffp-contract=off); results are bit-identical to the single-launch kernel and
-// to the CPU reference.  The FFT butterflies are the reference's (kiss_fft.cpp:112-304); only which lane evaluates
-// which butterfly changes, and the twiddles a lane needs are per-lane constants held in registers (with 64 lanes the
-// twiddle index of a butterfly depends on the lane only; the twelve of the last stage are fetched from the L1-resident
-// global table while the radix-3 stage runs), so no twiddle table is staged in LDS.
+// to the CPU reference (the band sums add explicit +0 padding terms: exact, a running sum that starts at +0 is never -0).
 #define PN_FE_G 1
 #include "pn_dsp_fe_helpers.inc"
 
 #define FS_WPB 4                        // waves (= concurrent streams) per block
 #define FS_THREADS (LANES * FS_WPB)
+#define FS_NF 1020                      // float2 per stream: 960 + 4 per 64 (layout phi)
+#define FS_PHI(i) ((i) + 4 * ((i) >> 6))
 
-struct alignas(16) FsTablesLds {
-  float win[PN_FRAME];           // 1920 B
-  float frac[PN_SPEC_BINS];      // 1600 B
-  int16_t bitrev[PN_NFFT];       // 1920 B
-  int16_t border[PN_NB + 2];
-  float comb_w[8];
-};
-struct alignas(16) FsWaveLds {
-  float2 fft[PN_NFFT];           // 7680 B
-};
+#ifndef PN_FS_WAVES_IN
+#define PN_FS_WAVES_IN 4                // waves per SIMD the register budget of spec_in is cut for (4: 128 registers)
+#endif
+#ifndef PN_FS_WAVES_OUT
+#define PN_FS_WAVES_OUT 3               // spec_out (28 comb-tap loads + the X spectrum on top): 168 registers, three 4-wave blocks per CU
+#endif
 struct FsShared {
-  FsTablesLds t;
-  FsWaveLds w[FS_WPB];
+  float2 f[FS_WPB][FS_NF];              // 8160 B per wave; the band-major operand arrays alias it after the FFT
+  float win[PN_FRAME];                  // 1920 B: half window (denoise.cpp:191-192), read four weights at a time
+  float frac[PN_SPEC_BINS];             // 1600 B: PnTables.bin_frac
+  unsigned pos[PN_SPEC_BINS];           // 1600 B: band_pos_a | band_pos_b << 16
 };
 
-__device__ __forceinline__ void fs_stage_tables(FsTablesLds &S, const PnTables *__restrict__ T) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < PN_NFFT; i += FS_THREADS) S.bitrev[i] = T->bitrev[i];
-  for (int i = tid; i < PN_FRAME; i += FS_THREADS) S.win[i] = T->half_window[i];
-  for (int i = tid; i < PN_SPEC_BINS; i += FS_THREADS) S.frac[i] = T->bin_frac[i];
-  if (tid < PN_NB + 2) S.border[tid] = T->border[tid];
-  if (tid < 8) S.comb_w[tid] = T->comb_hann[tid];
-  __syncthreads();
-}
-
-// The twiddles one lane ever needs (kiss_fft.cpp:139-304 index them by butterfly position; with 64 lanes and
-// butterfly b = lane + 64*iteration the position inside a stage depends on the lane only).
-struct FsTw {
-  float2 a4[3];        // radix-4, m=4:  tw[j*60*k], j = lane % 4, k = 1..3
-  float2 a16[3];       // radix-4, m=16: tw[j*15*k], j = lane % 16
-  float2 r3[2];        // radix-3, m=64: tw[5*lane], tw[10*lane]
-  float2 ya, yb;       // tw[192], tw[384]
-  float epi3;          // tw[320].y
-};
 __device__ __forceinline__ float2 fs_tw(const PnTables *__restrict__ T, int i) { return make_float2(T->tw[2 * i], T->tw[2 * i + 1]); }
-__device__ __forceinline__ void fs_load_tw(FsTw &W, const PnTables *__restrict__ T, int lane) {
-#pragma unroll
-  for (int k = 1; k <= 3; k++) { W.a4[k - 1] = fs_tw(T, (lane & 3) * 60 * k); W.a16[k - 1] = fs_tw(T, (lane & 15) * 15 * k); }
-  W.r3[0] = fs_tw(T, 5 * lane); W.r3[1] = fs_tw(T, 10 * lane);
-  W.ya = fs_tw(T, 192); W.yb = fs_tw(T, 384);
-  W.epi3 = T->tw[2 * 320 + 1];
+
+// radix-4 butterfly without twiddles (m = 1, kiss_fft.cpp:112-131), in place on f[0..3]
+__device__ __forceinline__ void fs_bfly4_m1(float2 *f) {
+  float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
+  s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
+  f0.x += f2.x; f0.y += f2.y;
+  s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
+  f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
+  f0.x += s1.x; f0.y += s1.y;
+  s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
+  f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
+  f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
+  f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
+}
+// radix-4 butterfly with twiddles (kiss_fft.cpp:139-166) on four elements held with stride `st` in a register array
+template <int st>
+__device__ __forceinline__ void fs_bfly4(float2 *f, float2 t1, float2 t2, float2 t3) {
+  float2 f0 = f[0], fm = f[st], f2m = f[2 * st], f3m = f[3 * st];
+  float2 s0, s1, s2, s3, s4, s5;
+  CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
+  s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
+  f0.x += s1.x; f0.y += s1.y;
+  s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
+  s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
+  f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
+  f0.x += s3.x; f0.y += s3.y;
+  fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
+  f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
+  f[0] = f0; f[st] = fm; f[2 * st] = f2m; f[3 * st] = f3m;
 }
 
-// 960-point FFT in LDS by the 64 lanes of one wave (opus_fft_impl, kiss_fft.cpp:518-564, factors 5,3,4,4,4); input
-// already scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585).  Same butterfly arithmetic as fe_fft960.
-__device__ __forceinline__ void fs_fft960(float2 *F, const FsTw &W, const PnTables *__restrict__ T, int l) {
-  PN_WAVE_SYNC();
-#pragma unroll 1                             // rolled: four waves per SIMD hide the latency, and 128 registers hold without spills
-  for (int it = 0; it < 4; it++) {           // radix-4, m=1 (kiss_fft.cpp:112-131): 240 butterflies
-    const int b = l + 64 * it;
-    if (b < 240) {
-      float2 *f = F + 4 * b;
-      float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
-      s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
-      f0.x += f2.x; f0.y += f2.y;
-      s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
-      f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
-      f0.x += s1.x; f0.y += s1.y;
-      s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
-      f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
-      f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
-      f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
-    }
-  }
-  PN_WAVE_SYNC();
+// Per-lane constants of the FFT that are worth a register each for the whole kernel (the 29 twiddles of P2/P3 are
+// fetched per transform from the 7.7 KB L1-resident table instead).
+struct FsLane {
+  int p1off[4];         // float2 index phi(4 b(n)) of stage-1 butterfly n = 4l + c  (b(n): digit reversal, kiss_fft.cpp:315-345)
+};
+__device__ __forceinline__ void fs_lane_init(FsLane &Z, const PnTables *__restrict__ T, int l) {
+  const int lc = l < 60 ? l : 59;
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {     // radix-4, m=4 (fstride 60) then m=16 (fstride 15) (139-166)
-    const int m = pass ? 16 : 4, mm = pass ? 64 : 16;
-    const float2 t1 = pass ? W.a16[0] : W.a4[0], t2 = pass ? W.a16[1] : W.a4[1], t3 = pass ? W.a16[2] : W.a4[2];
-#pragma unroll 1
-    for (int it = 0; it < 4; it++) {
-      const int b = l + 64 * it;
-      if (b < 240) {
-        const int i = b / m, j = b % m;
-        float2 *f = F + i * mm + j;
-        float2 f0 = f[0], fm = f[m], f2m = f[2 * m], f3m = f[3 * m];
-        float2 s0, s1, s2, s3, s4, s5;
-        CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
-        s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
-        f0.x += s1.x; f0.y += s1.y;
-        s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
-        s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
-        f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
-        f0.x += s3.x; f0.y += s3.y;
-        fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
-        f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
-        f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
+  for (int c = 0; c < 4; c++) {
+    const int n = 4 * lc + c;
+    const int n0 = n % 5, n1 = (n / 5) % 3, n2 = (n / 15) % 4, n3 = n / 60;
+    const int b = 48 * n0 + 16 * n1 + 4 * n2 + n3;
+    Z.p1off[c] = FS_PHI(4 * b);
+  }
+}
+
+// P1: x[k] = the four float4 of samples 4l + 240k (k = 0..3) of the 960-sample frame, lane l < 60.  Window, 1/960 scale,
+// first radix-4 stage, results to LDS (two 16-byte stores per butterfly).
+__device__ __forceinline__ void fs_fft_p1(float2 *F, const float *win, const FsLane &Z, const float4 *x, int l) {
+  const float scale = 1.f / PN_NFFT;
+  if (l < 60) {
+    // window weight of sample ii = 4l + c + 240k (apply_window, denoise.cpp:282-289): win[ii] for ii < 480, else
+    // win[959 - ii] — for k = 2, 3 the four weights are the float4 at 476 - 4l - 240(k-2), components reversed
+    float wq[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float4 q = *reinterpret_cast<const float4 *>(win + (k < 2 ? 4 * l + 240 * k : 476 - 4 * l - 240 * (k - 2)));
+      if (k < 2) { wq[k][0] = q.x; wq[k][1] = q.y; wq[k][2] = q.z; wq[k][3] = q.w; }
+      else { wq[k][0] = q.w; wq[k][1] = q.z; wq[k][2] = q.y; wq[k][3] = q.x; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float2 f[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float v = c == 0 ? x[k].x : (c == 1 ? x[k].y : (c == 2 ? x[k].z : x[k].w));
+        f[k] = make_float2(scale * (v * wq[k][c]), scale * 0.f);
       }
+      fs_bfly4_m1(f);
+      float4 *dst = reinterpret_cast<float4 *>(F + Z.p1off[c]);
+      dst[0] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+      dst[1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
     }
-    PN_WAVE_SYNC();
   }
-  float2 r5[3][4];                           // radix-5 twiddles tw[k*u], u = lane + 64*it: in flight during the radix-3 stage
+}
+
+// P2 + P3.  On return o[b][c] = bin u + 64b + 192c for c = 0, 1 (all b) and o2 = bin 384 + u (valid for u < 16).
+__device__ __forceinline__ void fs_fft_p23(float2 *F, const PnTables *__restrict__ T, int l_in, float2 (&o)[3][2], float2 &o2) {
+  // The twiddle indices depend on the lane only, i.e. the 29 loads are invariant in the caller's stream loop: without
+  // this opaque copy they are hoisted out of it and held in 58 registers for the whole kernel (spills at 128).
+  int l = l_in;
+  asm volatile("" : "+v"(l));
+  // twiddles of P2: issued first, the table is L1/L2-resident
+  const int jp = l & 3, blk = (l < 60 ? l : 59) >> 2;
+  float2 t2[3], t3[4][3];
 #pragma unroll
-  for (int it = 0; it < 3; it++)
+  for (int q = 1; q <= 3; q++) t2[q - 1] = fs_tw(T, jp * 60 * q);
 #pragma unroll
-    for (int k = 1; k <= 4; k++) r5[it][k - 1] = fs_tw(T, k * (l + 64 * it));
+  for (int ap = 0; ap < 4; ap++)
 #pragma unroll
-  for (int i = 0; i < 5; i++) {              // radix-3, m=64, fstride 5 (196-227): 320 butterflies, j = lane
-    float2 *f = F + i * 192 + l;
-    float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
-    CMUL(s1, fm, W.r3[0]); CMUL(s2, f2m, W.r3[1]);
+    for (int q = 1; q <= 3; q++) t3[ap][q - 1] = fs_tw(T, 15 * (4 * ap + jp) * q);
+  PN_WAVE_SYNC();
+  if (l < 60) {
+    float2 *f = F + 68 * blk + jp;                 // phi(64 blk + jp)
+    float2 v[16];                                  // v[4a + a'] = element 64 blk + 16a + 4a' + jp
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = f[4 * e];
+#pragma unroll
+    for (int a = 0; a < 4; a++) fs_bfly4<1>(v + 4 * a, t2[0], t2[1], t2[2]);          // m = 4: over a'
+#pragma unroll
+    for (int ap = 0; ap < 4; ap++) fs_bfly4<4>(v + ap, t3[ap][0], t3[ap][1], t3[ap][2]);   // m = 16: over a, j = 4a' + jp
+#pragma unroll
+    for (int e = 0; e < 16; e++) f[4 * e] = v[e];
+  }
+  float2 r3a = fs_tw(T, 5 * l), r3b = fs_tw(T, 10 * l), t5[3][4];
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+#pragma unroll
+    for (int q = 1; q <= 4; q++) t5[b][q - 1] = fs_tw(T, q * (l + 64 * b));
+  const float2 ya = fs_tw(T, 192), yb = fs_tw(T, 384);
+  const float epi3 = T->tw[2 * 320 + 1];
+  PN_WAVE_SYNC();
+  float2 w[3][5];                                  // w[b][c] = element u + 64b + 192c, u = lane
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+#pragma unroll
+    for (int c = 0; c < 5; c++) w[b][c] = F[l + 68 * b + 204 * c];      // phi(u + 64b + 192c) = u + 68b + 204c
+#pragma unroll
+  for (int c = 0; c < 5; c++) {                    // radix-3, m = 64 (kiss_fft.cpp:196-227): over b
+    float2 f0 = w[0][c], fm = w[1][c], f2m = w[2][c], s0, s1, s2, s3;
+    CMUL(s1, fm, r3a); CMUL(s2, f2m, r3b);
     s3.x = s1.x + s2.x; s3.y = s1.y + s2.y;
     s0.x = s1.x - s2.x; s0.y = s1.y - s2.y;
     fm.x = f0.x - s3.x * .5f; fm.y = f0.y - s3.y * .5f;
-    s0.x *= W.epi3; s0.y *= W.epi3;
+    s0.x *= epi3; s0.y *= epi3;
     f0.x += s3.x; f0.y += s3.y;
     f2m.x = fm.x + s0.y; f2m.y = fm.y - s0.x;
     fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
-    f[0] = f0; f[64] = fm; f[128] = f2m;
+    w[0][c] = f0; w[1][c] = fm; w[2][c] = f2m;
   }
-  PN_WAVE_SYNC();
-  {
-    const float2 ya = W.ya, yb = W.yb;       // radix-5, m=192, fstride 1 (259-304): 192 butterflies
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
-      float2 *f = F + l + 64 * it;
-      float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
-      float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
-      CMUL(s1, f1, r5[it][0]); CMUL(s2, f2, r5[it][1]); CMUL(s3, f3, r5[it][2]); CMUL(s4, f4, r5[it][3]);
-      s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
-      s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
-      s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
-      s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
-      f0.x = f0.x + (s7.x + s8.x);
-      f0.y = f0.y + (s7.y + s8.y);
-      s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
-      s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
-      s6.x = s10.y * ya.y + s9.y * yb.y;
-      s6.y = -(s10.x * ya.y + s9.x * yb.y);
-      f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
-      f4.x = s5.x + s6.x; f4.y = s5.y + s6.y;
+  for (int b = 0; b < 3; b++) {                    // radix-5, m = 192 (kiss_fft.cpp:259-304): over c; outputs 0, 1 (and 2 for b = 0)
+    float2 f0 = w[b][0], f1 = w[b][1], f2 = w[b][2], f3 = w[b][3], f4 = w[b][4];
+    float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10;
+    CMUL(s1, f1, t5[b][0]); CMUL(s2, f2, t5[b][1]); CMUL(s3, f3, t5[b][2]); CMUL(s4, f4, t5[b][3]);
+    s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
+    s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
+    s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
+    s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
+    f0.x = f0.x + (s7.x + s8.x);
+    f0.y = f0.y + (s7.y + s8.y);
+    s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
+    s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
+    s6.x = s10.y * ya.y + s9.y * yb.y;
+    s6.y = -(s10.x * ya.y + s9.x * yb.y);
+    f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
+    o[b][0] = f0; o[b][1] = f1;
+    if (b == 0) {
+      float2 s11, s12;
       s11.x = s0.x + (s7.x * yb.x + s8.x * ya.x);
       s11.y = s0.y + (s7.y * yb.x + s8.y * ya.x);
       s12.x = s9.y * ya.y - s10.y * yb.y;
       s12.y = s10.x * yb.y - s9.x * ya.y;
-      f2.x = s11.x + s12.x; f2.y = s11.y + s12.y;
-      f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
-      f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
+      o2.x = s11.x + s12.x; o2.y = s11.y + s12.y;
     }
   }
-  PN_WAVE_SYNC();
+}
+
+// ---- band reductions on band-major operands (denoise.cpp:89-160) ------------------------------------------------------------
+// bins of lane u: k(j) = u + 64 j, j = 0..5, and 384 + u for u < 16 (j = 6)
+#define FS_NBIN 7
+struct FsBands {
+  const float *frac;                   // LDS copies of the per-bin tables (block-shared)
+  const unsigned *pos;
+  int start, nq;                       // band lane (lane < 34): first float and number of quads of its operand run
+};
+__device__ __forceinline__ void fs_bands_init(FsBands &B, const FsShared &SH, const PnTables *__restrict__ T, int l) {
+  B.frac = SH.frac; B.pos = SH.pos;
+  B.start = l < PN_NB ? T->band_start[l] : 0;
+  B.nq = l < PN_NB ? T->band_nq[l] : 0;
+}
+// zero the layout (its pad slots must read +0), then scatter the per-bin terms of tmp[j] (bin k(j)) into it
+__device__ __forceinline__ void fs_bands_fill(float *C, const FsBands &B, const float *tmp, int l) {
+#pragma unroll
+  for (int it = 0; it < (PN_BAND_LAYOUT_FLOATS / 4 + 63) / 64; it++) {
+    const int q = l + 64 * it;
+    if (q < PN_BAND_LAYOUT_FLOATS / 4) *reinterpret_cast<float4 *>(C + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float fr[FS_NBIN]; unsigned ps[FS_NBIN];
+#pragma unroll
+  for (int j = 0; j < FS_NBIN; j++) {
+    const int k = (j < 6) ? l + 64 * j : (l < 16 ? 384 + l : 0);
+    fr[j] = B.frac[k]; ps[j] = B.pos[k];
+  }
+#pragma unroll
+  for (int j = 0; j < FS_NBIN; j++) {
+    if (j == 6 && l >= 16) continue;
+    const float fa = fr[j] * tmp[j], fb = (1 - fr[j]) * tmp[j];
+    C[ps[j] & 0xffff] = fa;
+    C[ps[j] >> 16] = fb;
+  }
+}
+// the chains: lane b < 34 sums its run in order; NARR arrays at C, C + PN_BAND_LAYOUT_FLOATS, ...
+template <int NARR>
+__device__ __forceinline__ void fs_bands_sum(const float *C, const FsBands &B, int l, float *sum) {
+#pragma unroll
+  for (int h = 0; h < NARR; h++) sum[h] = 0;
+  const float *p = C + B.start;
+  for (int q = 0; q < 25; q++) {                    // 25 = the longest run (band 32: 45 + 51 bins)
+    if (q < B.nq) {
+#pragma unroll
+      for (int h = 0; h < NARR; h++) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + h * PN_BAND_LAYOUT_FLOATS + 4 * q);
+        sum[h] += v.x; sum[h] += v.y; sum[h] += v.z; sum[h] += v.w;
+      }
+    }
+  }
+  if (l == 0 || l == PN_NB - 1)
+#pragma unroll
+    for (int h = 0; h < NARR; h++) sum[h] *= 2;
 }
 
 // ---- spectral-in: history write + look-ahead FFT + band energies ------------------------------------------------------
 template <typename TIn>
-__global__ __launch_bounds__(FS_THREADS, 4) void pn_fe_spec_in_kernel(
+__global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_IN) void pn_fe_spec_in_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w,
     const TIn *__restrict__ in, long long in_stride, float i16_scale,
     float *__restrict__ hist, float2 *__restrict__ yring, float *__restrict__ eyring) {
   __shared__ FsShared SH;
-  const int tid = threadIdx.x, l = tid & (LANES - 1), wave = tid >> 6;
-  fs_stage_tables(SH.t, T);
-  const FsTablesLds &S = SH.t;
-  float2 *F = SH.w[wave].fft;
-  FsTw W;
-  fs_load_tw(W, T, l);
+  const int tid = threadIdx.x, l = tid & (LANES - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the stream pointers below are scalar
+  float2 *F = SH.f[wave];
+  float *C = reinterpret_cast<float *>(F);
+  for (int i = tid; i < PN_FRAME; i += FS_THREADS) SH.win[i] = T->half_window[i];
+  for (int i = tid; i < PN_SPEC_BINS; i += FS_THREADS) {
+    SH.frac[i] = T->bin_frac[i];
+    SH.pos[i] = (unsigned)T->band_pos_a[i] | ((unsigned)T->band_pos_b[i] << 16);
+  }
+  __syncthreads();
+  FsLane Z; FsBands B;
+  fs_lane_init(Z, T, l);
+  fs_bands_init(B, SH, T, l);
   const int new_slot = frame_t % PN_HIST_FRAMES;
   const int prev_slot = (frame_t + PN_HIST_FRAMES - 1) % PN_HIST_FRAMES;
-  const float scale = 1.f / PN_NFFT;
+  const int lc = l < 60 ? l : 59;
   for (int s = blockIdx.x * FS_WPB + wave; s < n_streams; s += gridDim.x * FS_WPB) {
     float *h = hist + (size_t)s * PN_HIST_STRIDE;
-    // window = the previous frame (ring slot t-1) | the new frame: 2 x 120 float4, lane l takes float4 l and l + 64
-    float4 ov[2], nv[2];
+    // frame = the previous input frame (ring slot t-1) | the new one; lane l < 60 takes samples 4l + 240k
+    float4 x[4];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int i4 = l + 64 * it, i4c = i4 < PN_FRAME / 4 ? i4 : 0;
-      ov[it] = *reinterpret_cast<const float4 *>(h + prev_slot * PN_FRAME + 4 * i4c);
+    for (int k = 0; k < 2; k++) x[k] = *reinterpret_cast<const float4 *>(h + prev_slot * PN_FRAME + 4 * lc + 240 * k);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
       if (sizeof(TIn) == 2) {
-        const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * in_stride + 4 * i4c);
+        const short4 q = *reinterpret_cast<const short4 *>(in + (size_t)s * in_stride + 4 * lc + 240 * k);
         // a power-of-two scale: the product is exact, == the reference's division (main.cpp:34)
-        nv[it] = make_float4(((float)q.x) * i16_scale, ((float)q.y) * i16_scale, ((float)q.z) * i16_scale, ((float)q.w) * i16_scale);
+        x[2 + k] = make_float4(((float)q.x) * i16_scale, ((float)q.y) * i16_scale, ((float)q.z) * i16_scale, ((float)q.w) * i16_scale);
       } else {
-        nv[it] = *reinterpret_cast<const float4 *>(in + (size_t)s * in_stride + 4 * i4c);
+        x[2 + k] = *reinterpret_cast<const float4 *>(in + (size_t)s * in_stride + 4 * lc + 240 * k);
       }
     }
+    if (l < 60) {                                  // the shift+append of denoise.cpp:388-389 is one ring-slot write
 #pragma unroll
-    for (int it = 0; it < 2; it++) {           // the shift+append of denoise.cpp:388-389 is one ring-slot write
-      const int i4 = l + 64 * it;
-      if (i4 < PN_FRAME / 4) {
-        *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * i4) = nv[it];
-        if (new_slot == 0 && i4 < 2) *reinterpret_cast<float4 *>(h + PN_HIST + 4 * i4) = nv[it];   // mirror of the ring's first 8 samples
+      for (int k = 0; k < 2; k++) {
+        *reinterpret_cast<float4 *>(h + new_slot * PN_FRAME + 4 * l + 240 * k) = x[2 + k];
+        if (new_slot == 0 && k == 0 && l < 2) *reinterpret_cast<float4 *>(h + PN_HIST + 4 * l) = x[2];   // mirror of the ring's first 8 samples
       }
     }
-#pragma unroll
-    for (int half = 0; half < 2; half++)
-#pragma unroll
-      for (int it = 0; it < 2; it++) {
-        const int i4 = l + 64 * it;
-        if (i4 >= PN_FRAME / 4) continue;
-        const float4 v4 = half ? nv[it] : ov[it];
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int ii = half * PN_FRAME + 4 * i4 + c;
-          const float w = S.win[ii < PN_FRAME ? ii : PN_WINDOW - 1 - ii];   // apply_window 282-289
-          F[S.bitrev[ii]] = make_float2(scale * (vv[c] * w), scale * 0.f);
-        }
-      }
-    fs_fft960(F, W, T, l);
+    fs_fft_p1(F, SH.win, Z, x, l);
+    float2 o[3][2], o2;
+    fs_fft_p23(F, T, l, o, o2);
     float2 *yw = yring + ((size_t)slot_w * n_streams + s) * PN_SPEC_BINS;
+    float tmp[FS_NBIN];
 #pragma unroll
-    for (int it = 0; it < 7; it++) { const int k = l + 64 * it; if (k < PN_SPEC_BINS) yw[k] = F[k]; }
-    const float e = fe_band<false>(S, F, nullptr, l);
+    for (int j = 0; j < 6; j++) {
+      const float2 a = o[j % 3][j / 3];            // bin u + 64 j = u + 64 (j % 3) + 192 (j / 3)
+      yw[l + 64 * j] = a;
+      float t = a.x * a.x; t += a.y * a.y; tmp[j] = t;
+    }
+    if (l < 16) yw[384 + l] = o2;
+    { float t = o2.x * o2.x; t += o2.y * o2.y; tmp[6] = t; }
+    PN_WAVE_SYNC();
+    fs_bands_fill(C, B, tmp, l);
+    PN_WAVE_SYNC();
+    float e;
+    fs_bands_sum<1>(C, B, l, &e);
     if (l < PN_NB) eyring[((size_t)slot_w * n_streams + s) * 36 + l] = e;
     PN_WAVE_SYNC();
   }
 }
 
 // ---- spectral-out: comb filter at the pitch period + window + FFT -> P, Ep, Exp, features ---------------------------------
-__global__ __launch_bounds__(FS_THREADS, 4) void pn_fe_spec_out_kernel(
+__global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
     const float *__restrict__ hist, const float2 *__restrict__ yring, const float *__restrict__ eyring,
     const int *__restrict__ last_period,      // written by the pitch kernel of this frame
     float2 *__restrict__ Pspec, float *__restrict__ feat, int *__restrict__ silence, float *__restrict__ aux) {
   __shared__ FsShared SH;
-  const int tid = threadIdx.x, l = tid & (LANES - 1), wave = tid >> 6;
-  fs_stage_tables(SH.t, T);
-  const FsTablesLds &S = SH.t;
-  float2 *F = SH.w[wave].fft;
-  float *prod = reinterpret_cast<float *>(F) + 960;     // per-bin X.P products: bins live in F[0,400) = floats [0,800)
-  FsTw W;
-  fs_load_tw(W, T, l);
-  const int base_slot = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
-  const float scale = 1.f / PN_NFFT;
+  const int tid = threadIdx.x, l = tid & (LANES - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the stream pointers below are scalar
+  float2 *F = SH.f[wave];
+  float *C = reinterpret_cast<float *>(F);
+  for (int i = tid; i < PN_FRAME; i += FS_THREADS) SH.win[i] = T->half_window[i];
+  for (int i = tid; i < PN_SPEC_BINS; i += FS_THREADS) {
+    SH.frac[i] = T->bin_frac[i];
+    SH.pos[i] = (unsigned)T->band_pos_a[i] | ((unsigned)T->band_pos_b[i] << 16);
+  }
+  __syncthreads();
+  FsLane Z; FsBands B;
+  fs_lane_init(Z, T, l);
+  fs_bands_init(B, SH, T, l);
+  float cw[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) cw[k] = T->comb_hann[k];
+  const int base_slot0 = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
+  const int lc = l < 60 ? l : 59;
   for (int s = blockIdx.x * FS_WPB + wave; s < n_streams; s += gridDim.x * FS_WPB) {
     const float *h = hist + (size_t)s * PN_HIST_STRIDE;
     const int pitch_index = last_period[s];
+    int base_slot = base_slot0;
+    asm volatile("" : "+v"(base_slot));              // keeps the 28 ring offsets below from being hoisted out of the stream loop
     const float2 *Xr = yring + ((size_t)slot_r * n_streams + s) * PN_SPEC_BINS;   // X(t)  = Y(t-5)
     const float Ex = l < PN_NB ? eyring[((size_t)slot_r * n_streams + s) * 36 + l] : 0.f;   // Ex(t) = Ey(t-5)
     const float Ey = l < PN_NB ? eyring[((size_t)slot_w * n_streams + s) * 36 + l] : 0.f;   // Ey of this frame
-    // comb filter (denoise.cpp:416-422): lane l filters 4 consecutive samples per group, groups l + 64*it (240 groups);
-    // one unaligned dwordx4 load per tap (the ring carries an 8-sample mirror)
-#pragma unroll 1
-    for (int q0 = 0; q0 < 4; q0 += 2) {
+    // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240k .. +3, k = 0..3; one unaligned dwordx4
+    // load per tap (the ring carries an 8-sample mirror).  Two k at a time: 14 loads in flight.
+    float4 x[4];
+    int bs = base_slot;
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += 2) {
+      // the second half's ring offsets are made to depend on the first half's result: its 14 loads (56 registers) are
+      // issued after the first half's arithmetic instead of next to the first 14
+      if (k0) asm volatile("" : "+v"(bs) : "v"(x[1].w));
       fe_f4u cv[2][7];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int gi = l + 64 * (q0 + q), gc = gi < PN_WINDOW / 4 ? gi : 0;
+      for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int k = -PN_COMB_M; k <= PN_COMB_M; k++)
-          cv[q][k + PN_COMB_M] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(2400 - pitch_index * k + 4 * gc, base_slot));
-      }
+          cv[q][k + PN_COMB_M] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(2400 - pitch_index * k + 4 * lc + 240 * (k0 + q), bs));
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        const int gi = l + 64 * (q0 + q);
-        if (gi >= PN_WINDOW / 4) continue;
+        float p[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          const int i = 4 * gi + c;
-          float p = 0;
+          float acc = 0;
 #pragma unroll
-          for (int k = 0; k < 7; k++) p += cv[q][k][c] * S.comb_w[k];
-          const float v = p * S.win[i < PN_FRAME ? i : PN_WINDOW - 1 - i];
-          F[S.bitrev[i]] = make_float2(scale * v, scale * 0.f);
+          for (int k = 0; k < 7; k++) acc += cv[q][k][c] * cw[k];
+          p[c] = acc;
         }
+        x[k0 + q] = make_float4(p[0], p[1], p[2], p[3]);
       }
     }
-    fs_fft960(F, W, T, l);
-    {
-      float2 xv[7];
+    fs_fft_p1(F, SH.win, Z, x, l);
+    float2 o[3][2], o2;
+    fs_fft_p23(F, T, l, o, o2);
+    float2 xv[FS_NBIN];
 #pragma unroll
-      for (int it = 0; it < 7; it++) { const int k = l + 64 * it; xv[it] = Xr[k < PN_SPEC_BINS ? k : 0]; }
+    for (int j = 0; j < FS_NBIN; j++) xv[j] = Xr[(j < 6) ? l + 64 * j : (l < 16 ? 384 + l : 0)];
+    float tp[FS_NBIN], tx[FS_NBIN];
 #pragma unroll
-      for (int it = 0; it < 7; it++) {
-        const int k = l + 64 * it;
-        if (k >= PN_SPEC_BINS) continue;
-        const float2 P = F[k];
-        Pspec[(size_t)s * PN_SPEC_BINS + k] = P;
-        float tmp = xv[it].x * P.x;            // compute_band_corr's per-bin term (denoise.cpp:136-137)
-        tmp += xv[it].y * P.y;
-        prod[k] = tmp;
-      }
+    for (int j = 0; j < FS_NBIN; j++) {
+      const float2 P = j < 6 ? o[j % 3][j / 3] : o2;
+      if (j < 6 || l < 16) Pspec[(size_t)s * PN_SPEC_BINS + (j < 6 ? l + 64 * j : 384 + l)] = P;
+      float t = P.x * P.x; t += P.y * P.y; tp[j] = t;        // compute_band_energy's per-bin term (denoise.cpp:100-101)
+      float u = xv[j].x * P.x; u += xv[j].y * P.y; tx[j] = u;  // compute_band_corr's (136-137)
     }
     PN_WAVE_SYNC();
-    const float Ep = fe_band<false>(S, F, nullptr, l);
-    float Exp = fe_band<true>(S, nullptr, prod, l);
+    fs_bands_fill(C, B, tp, l);
+    fs_bands_fill(C + PN_BAND_LAYOUT_FLOATS, B, tx, l);
+    PN_WAVE_SYNC();
+    float sums[2];
+    fs_bands_sum<2>(C, B, l, sums);
+    const float Ep = sums[0];
+    float Exp = sums[1];
     float *f = feat + (size_t)s * PN_FEAT_STRIDE;
     if (l < PN_NB) {
       // double island, denoise.cpp:427
@@ -322,25 +434,25 @@ __global__ __launch_bounds__(FS_THREADS, 4) void pn_fe_spec_out_kernel(
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
-static int fs_grid(int n_streams) {
+static int fs_grid(int n_streams, int blocks_per_cu) {
   const int need = (n_streams + FS_WPB - 1) / FS_WPB;
-  const int cap = 256 * 4;                               // four LDS-resident blocks on each of 256 CUs
+  const int cap = 256 * blocks_per_cu;                   // resident 4-wave blocks on 256 CUs
   return need < cap ? need : cap;
 }
 void pn_launch_fe_spec_in(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
                           long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring) {
   const int frame_t = (int)(frame % PN_HIST_FRAMES), slot_w = (int)(frame % 6);
   if (in_is_i16)
-    hipLaunchKernelGGL(pn_fe_spec_in_kernel<int16_t>, dim3(fs_grid(n_streams)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_fe_spec_in_kernel<int16_t>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
                        slot_w, (const int16_t *)in, in_stride, i16_scale, hist, yring, eyring);
   else
-    hipLaunchKernelGGL(pn_fe_spec_in_kernel<float>, dim3(fs_grid(n_streams)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_fe_spec_in_kernel<float>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
                        slot_w, (const float *)in, in_stride, i16_scale, hist, yring, eyring);
 }
 void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const float *hist,
                            const float2 *yring, const float *eyring, const int *last_period, float2 *Ps, float *feat,
                            int *silence, float *aux) {
   const int frame_t = (int)(frame % PN_HIST_FRAMES), slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
-  hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
+  hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams, PN_FS_WAVES_OUT)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
                      slot_r, hist, yring, eyring, last_period, Ps, feat, silence, aux);
 }

@@ -72,6 +72,22 @@ void pn_build_tables(PnTables *t) {
         if (bin < PN_SPEC_BINS) { t->bin_band[bin] = (uint8_t)i; t->bin_frac[bin] = (float)j / band_size; }
       }
     }
+    // band-major operand layout (see PnTables): band b = [interval b-1, frac part][interval b, (1-frac) part]
+    int pos = 0;
+    for (int b = 0; b < PN_NB; b++) {
+      t->band_start[b] = (uint16_t)pos;
+      const int n1 = b >= 1 ? border[b] - border[b - 1] : 0, n2 = b <= PN_NB - 2 ? border[b + 1] - border[b] : 0;
+      for (int j = 0; j < n1; j++) t->band_pos_a[border[b - 1] + j] = (uint16_t)(pos + j);
+      pos += (n1 + 3) / 4 * 4;
+      for (int j = 0; j < n2; j++) t->band_pos_b[border[b] + j] = (uint16_t)(pos + j);
+      pos += (n2 + 3) / 4 * 4;
+      t->band_nq[b] = (uint16_t)((pos - t->band_start[b]) / 4);
+    }
+    if (pos != PN_BAND_LAYOUT_FLOATS || border[PN_NB - 1] != PN_SPEC_BINS) {
+      fprintf(stderr, "percepnet_hip: band layout is %d floats / last border %d, the kernels are built for %d / %d\n", pos,
+              border[PN_NB - 1], PN_BAND_LAYOUT_FLOATS, PN_SPEC_BINS);
+      abort();
+    }
   }
   for (int i = 0; i <= 200; i++) {
     char buf[32];

@@ -47,14 +47,21 @@ SETS = {
     "scale2_gate_biased": lambda: _biased(13, 2.0),
     "scale6_saturating": lambda: weights.random_layers(14, scale=6.0),
 }
-ONE_STEP_TOL = 2e-5          # max |dg,r| of one network step from identical state, any weight set (the north_star's g,r tolerance)
+# max |dg,r| of ONE network step from identical state.  Measured (profiles/r03c_parity_stress_*.json): 2.5e-6 / 2.7e-6 /
+# 3.2e-6 for the x2 / gate-biased / x3 sets, 6.0e-5 for the x6 saturating set (pre-activations of +-100: the fused
+# multiply-add's rounding differs from mul-then-add by an ulp of THAT magnitude, and the steep part of the table passes it on).
+ONE_STEP_TOL = {"scale2": 2e-5, "scale3": 2e-5, "scale2_gate_biased": 2e-5, "scale6_saturating": 2e-4}
 # free-running (max |dPCM| in LSB, max |dg,r|) asserted per set; None = chaotic set, recorded only — measured values are
 # in profiles/r03*_parity_stress_*.json
+# Measured free-running over 10 s: x2, gate-biased, x3: max 1 LSB, |dg,r| <= 6.3e-6 — the north_star tolerance holds well
+# beyond the near-init benchmark weights.  x6 saturating: |dg,r| up to 1.7e-3 (99.99 % below 3.7e-4); its output hits the
+# int16 rails, where the reference's wrap-around cast (main.cpp:36) turns a tiny float difference into +-65535, so its PCM
+# is compared as a circular distance.
 BOUNDS = {
-    "scale2": (None, None),
-    "scale3": (None, None),
-    "scale2_gate_biased": (None, None),
-    "scale6_saturating": (None, None),
+    "scale2": (1, 2e-5),
+    "scale3": (1, 2e-5),
+    "scale2_gate_biased": (1, 2e-5),
+    "scale6_saturating": (None, 5e-3),
 }
 
 
@@ -89,6 +96,7 @@ def test_mfma_mode_vs_oracle_on_other_weight_sets(name):
     cm.close(); cs.close()
     model.close()
     d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    d = np.minimum(d, 65536 - d)                   # circular: the reference's float->int16 cast wraps (main.cpp:36)
     dg = np.abs(gr - rg)
     by_s = [float(dg[:, k:k + 100].max()) for k in range(0, T, 100)]
     stats = {
@@ -97,7 +105,7 @@ def test_mfma_mode_vs_oracle_on_other_weight_sets(name):
         "weights": name, "streams": B, "frames": T,
         "g_range": [float(rg[..., :34].min()), float(rg[..., :34].max())], "r_range": [float(rg[..., 34:].min()), float(rg[..., 34:].max())],
         "g_std_over_time": float(rg[..., :34].std()),
-        "max_abs_delta_pcm_lsb": int(d.max()), "pcm_samples": int(d.size),
+        "max_abs_delta_pcm_lsb_circular": int(d.max()), "pcm_samples": int(d.size),
         "pcm_delta_histogram_lsb": np.bincount(np.minimum(d, 16).ravel().astype(np.int64), minlength=17).tolist(),
         "max_abs_delta_gr": float(dg.max()), "mean_abs_delta_gr": float(dg.mean()),
         "p9999_abs_delta_gr": float(np.quantile(dg, 0.9999)),
@@ -107,12 +115,12 @@ def test_mfma_mode_vs_oracle_on_other_weight_sets(name):
     _record(f"stress_{name}", stats)
     assert np.isfinite(gr).all()
     assert np.array_equal(feat.view(np.uint32), rf.view(np.uint32)) and np.array_equal(sil, rs)
-    assert one.max() <= ONE_STEP_TOL, float(one.max())
+    assert one.max() <= ONE_STEP_TOL[name], float(one.max())
     assert max(by_s) <= 8 * max(by_s[0], 1e-6) + 1e-6, by_s          # no drift: the difference does not grow with time
     lsb, tol = BOUNDS[name]
     if lsb is not None:
         assert d.max() <= lsb, int(d.max())
-        assert dg.max() <= tol, float(dg.max())
+    assert dg.max() <= tol, float(dg.max())
 
 
 def test_fp16_bound_from_a_larger_sample(blob, oracle):

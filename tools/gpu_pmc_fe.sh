@@ -14,7 +14,7 @@ d = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/s*/k_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ","")
-        if k.startswith("pn_frontend") or k.startswith("pn_backend"):
+        if k.startswith("pn_frontend") or k.startswith("pn_backend") or k.startswith("pn_fe_"):
             d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             d[k]["dur_us"].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 for k, v in d.items():
