@@ -603,6 +603,41 @@ def test_small_batch_and_batch_gemm_kernel_families_agree_bit_for_bit(model, ora
     assert np.abs(res["small"][1] - rg).max() <= GR_TOL
 
 
+def test_front_end_kernel_families_agree_bit_for_bit(model, oracle):
+    """Three front ends compute compute_frame_features (denoise.cpp:372-434): the phase-split kernels (pn_dsp_fe_split_*.hip:
+    spec_in / pitch / spec_out, the default above 2048 streams), and the single-launch kernel with four or two streams
+    per wavefront.  Different lane mappings, a differently organised FFT (three register-fused passes vs five stages), a
+    sparse fine pitch search, band sums over padded band-major operands — and the same reference-order arithmetic: every
+    feature word, silence flag, PCM sample and g/r tap must be bit-identical, and equal to the oracle's features.  Ragged
+    batch over a full history-ring wrap (14 > 12 frames), extreme-level streams included."""
+    B, T = 301, 14
+    pcm = synth.synth_batch(B, T, first_stream=60)
+    pcm[7] = np.where((np.arange(T * 480) // 120) % 2 == 0, 32767, -32768).astype(np.int16)     # full-scale square wave
+    pcm[8] = 0
+    res = {}
+    for fam in ("split", "mono", "g2"):
+        os.environ["PERCEPNET_FE"] = fam
+        try:
+            ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+        finally:
+            del os.environ["PERCEPNET_FE"]
+        assert ctx.describe()["frontend"] == {"split": "split", "mono": "g4", "g2": "g2"}[fam]
+        outs, grs, feats, sils = [], [], [], []
+        for t in range(T):
+            o, g = ctx.process_i16(pcm[:, t * 480:(t + 1) * 480])
+            f, s_ = ctx.read_features()
+            outs.append(o); grs.append(g); feats.append(f); sils.append(s_)
+        res[fam] = (np.stack(outs), np.stack(grs).view(np.uint32), np.stack(feats).view(np.uint32), np.stack(sils))
+        ctx.close()
+    for fam in ("mono", "g2"):
+        for a, b in zip(res["split"], res[fam]):
+            assert np.array_equal(a, b), fam
+    _, _, rf, rs = oracle.run_batch(pcm)
+    assert np.array_equal(res["split"][2], np.ascontiguousarray(rf.transpose(1, 0, 2)).view(np.uint32))
+    assert np.array_equal(res["split"][3], rs.T)
+    assert (rs == 0).any()                       # non-silent frames: the comb-filtered spectrum mattered
+
+
 def test_extreme_inputs_strict_bit_exact(model, oracle):
     """Inputs at the edges of the int16 range: full-scale square wave, alternating +-32768/32767, a lone impulse, DC at
     both rails, white noise at full scale.  The CLI's float->int16 conversion truncates and WRAPS (main.cpp:36, no
