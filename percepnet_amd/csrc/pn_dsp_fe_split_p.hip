@@ -33,7 +33,111 @@
 #define FP_XC (FP_SCR + 0)              //   [0,176)   coarse xcorr (lag 11 l + c), later p|q of yy_lookup (128)
 #define FP_D (FP_SCR + 176)             //   [176,324) d[] of the coarse best-pitch scan (148); later the 64-float d block of the fine scan
 #define FP_SQ (FP_SCR + 324)            //   [324,388) 64-float broadcast scratch
+#ifndef PN_FP_ROWS
+#define PN_FP_ROWS 0                    // 1: consecutive-lag chains (autocorrelation, final three) read one row per 12 steps and shift it with DPP
+                                        //    (fewer LDS cycles, one more VALU op per step: pays only while the LDS pipe is the limiter)
+#endif
+#ifndef PN_FP_PAIRS
+#define PN_FP_PAIRS 1                   // 1: remove_doubling's arbitrary-lag chains read aligned pairs (fp_chain2_pairs)
+#endif
 #define FP_SLICE 1264                   // 5056 bytes; 16 streams = 80 896 bytes per block, two blocks per CU
+
+
+// ---- serial chains with few LDS cycles --------------------------------------------------------------------------------
+// (profiles/r03c_fe_split_v1_pmc.txt: this kernel is bound by the CU's LDS pipe; 42 % of its LDS cycles were bank conflicts
+// of remove_doubling's per-lane arbitrary-lag reads, 9.5 conflict cycles per ds_read_b32.)
+
+// v[lane] -> v[lane + n] within the 16-lane row (n = 0..15; lanes whose source falls off the row keep garbage that
+// their caller never uses): v_mov_b32_dpp row_shl:n, which the compiler folds into the multiply that consumes it
+template <int n>
+__device__ __forceinline__ float fp_row_shl(float v) {
+  if (n == 0) return v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + (n & 15), 0xf, 0xf, true));
+}
+// acc + sum_{j<N} a[j] * b[lane k: j + k], adds strictly in j order, for chains whose per-lane operands are CONSECUTIVE:
+// lane k of the group (k <= 15 - 11) correlates the group-uniform a[] against b[j + k].  One ds_read_b32 (the 16 lanes read
+// b[j0 .. j0+15]) then serves 12 steps through row shifts; a[] is read four steps per ds_read_b128 at a uniform address.
+// a + j0 must be 16-byte aligned for every block start j0 (multiples of 12: a itself 16-byte aligned).
+template <int N>
+__device__ __forceinline__ float fp_chain_rows(const float *a, const float *b, int l, float acc) {
+  static_assert(N % 4 == 0, "N");
+  constexpr int NB12 = N / 12, R = N % 12;
+  float4 a0[3], a1[3]; float v0, v1;
+#define FP_CR_LOAD(av, vv, blk) do {                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (av)[q_] = *reinterpret_cast<const float4 *>(a + 12 * (blk) + 4 * q_); \
+    (vv) = b[12 * (blk) + l];                                                                  \
+  } while (0)
+#define FP_CR_MAC(av, vv) do {                                                                  \
+    acc = acc + (av)[0].x * fp_row_shl<0>(vv); acc = acc + (av)[0].y * fp_row_shl<1>(vv);       \
+    acc = acc + (av)[0].z * fp_row_shl<2>(vv); acc = acc + (av)[0].w * fp_row_shl<3>(vv);       \
+    acc = acc + (av)[1].x * fp_row_shl<4>(vv); acc = acc + (av)[1].y * fp_row_shl<5>(vv);       \
+    acc = acc + (av)[1].z * fp_row_shl<6>(vv); acc = acc + (av)[1].w * fp_row_shl<7>(vv);       \
+    acc = acc + (av)[2].x * fp_row_shl<8>(vv); acc = acc + (av)[2].y * fp_row_shl<9>(vv);       \
+    acc = acc + (av)[2].z * fp_row_shl<10>(vv); acc = acc + (av)[2].w * fp_row_shl<11>(vv);     \
+  } while (0)
+  FP_CR_LOAD(a0, v0, 0);
+#pragma unroll 1
+  for (int blk = 0; blk < NB12; blk += 2) {
+    if (blk + 1 < NB12) FP_CR_LOAD(a1, v1, blk + 1);
+    FP_CR_MAC(a0, v0);
+    if (blk + 2 < NB12) FP_CR_LOAD(a0, v0, blk + 2);
+    if (blk + 1 < NB12) FP_CR_MAC(a1, v1);
+  }
+  if (R) {                                          // R in {4, 8}
+    float4 ar[2]; float vr;
+#pragma unroll
+    for (int q = 0; q < R / 4; q++) ar[q] = *reinterpret_cast<const float4 *>(a + 12 * NB12 + 4 * q);
+    vr = b[12 * NB12 + l];
+    acc = acc + ar[0].x * fp_row_shl<0>(vr); acc = acc + ar[0].y * fp_row_shl<1>(vr);
+    acc = acc + ar[0].z * fp_row_shl<2>(vr); acc = acc + ar[0].w * fp_row_shl<3>(vr);
+    if (R > 4) {
+      acc = acc + ar[1].x * fp_row_shl<4>(vr); acc = acc + ar[1].y * fp_row_shl<5>(vr);
+      acc = acc + ar[1].z * fp_row_shl<6>(vr); acc = acc + ar[1].w * fp_row_shl<7>(vr);
+    }
+  }
+#undef FP_CR_LOAD
+#undef FP_CR_MAC
+  return acc;
+}
+
+// Two chains sharing the uniform operand, per-lane operands at ARBITRARY lags (remove_doubling's 28 + 2 inner products):
+// acc1 += a . b1, acc2 += a . b2, adds strictly in j order.  Every lane reads its operands as 8-byte ALIGNED pairs
+// (ds_read_b64: 64 banks, half the instructions) and picks the run that starts at its own parity (o1 / o2 = the parity of
+// the lane's first element: 1 = its run starts at the second float of the first pair): one v_cndmask per operand
+// instead of ~10 LDS bank-conflict cycles per scalar read.  b1 - o1, b2 - o2 must be 8-byte aligned.
+template <int N>
+__device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1, bool o1, const float *b2, bool o2,
+                                                float &acc1, float &acc2) {
+  constexpr int U = 16, NF = N / U;
+  static_assert(N % U == 0 && NF % 2 == 0, "N");
+  const float2 *p1 = reinterpret_cast<const float2 *>(b1 - (o1 ? 1 : 0)), *p2 = reinterpret_cast<const float2 *>(b2 - (o2 ? 1 : 0));
+  float4 a0[4], a1[4]; float2 r0[9], s0[9], r1[9], s1[9];
+#define FP_C2_LOAD(av, rv, sv, blk) do {                                                        \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
+    _Pragma("unroll") for (int u_ = 0; u_ < 9; u_++) { (rv)[u_] = p1[8 * (blk) + u_]; (sv)[u_] = p2[8 * (blk) + u_]; } \
+  } while (0)
+#define FP_C2_AT(rv, o_, u_) ((o_) ? (((u_) & 1) ? (rv)[((u_) + 1) >> 1].x : (rv)[(u_) >> 1].y) : (((u_) & 1) ? (rv)[(u_) >> 1].y : (rv)[(u_) >> 1].x))
+#define FP_C2_MAC(av, rv, sv) do {                                                              \
+    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                          \
+      const float ax_[4] = {(av)[v_].x, (av)[v_].y, (av)[v_].z, (av)[v_].w};                    \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; e_++) {                                        \
+        acc1 = acc1 + ax_[e_] * FP_C2_AT(rv, o1, 4 * v_ + e_);                                  \
+        acc2 = acc2 + ax_[e_] * FP_C2_AT(sv, o2, 4 * v_ + e_);                                  \
+      }                                                                                         \
+    }                                                                                           \
+  } while (0)
+  FP_C2_LOAD(a0, r0, s0, 0);
+#pragma unroll 1
+  for (int blk = 0; blk < NF; blk += 2) {
+    FP_C2_LOAD(a1, r1, s1, blk + 1);
+    FP_C2_MAC(a0, r0, s0);
+    if (blk + 2 < NF) FP_C2_LOAD(a0, r0, s0, blk + 2);
+    FP_C2_MAC(a1, r1, s1);
+  }
+#undef FP_C2_LOAD
+#undef FP_C2_AT
+#undef FP_C2_MAC
+}
 
 // find_best_pitch for the fine search (pitch.cpp:46-104 on the sparse xcorr of pitch.cpp:344-361): only the <= 10 lags
 // within +-2 of twice the two coarse candidates carry a correlation, every other entry is 0 and skipped by the
@@ -170,7 +274,11 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
       float ac[5];
       {
         const int lag = l < 4 ? l : 4;
+#if PN_FP_ROWS
+        float ack = fp_chain_rows<860>(raw, raw, l, 0.f);     // lane k <= 4: sum_i raw[i] * raw[i + k]; lanes > 4 are never read
+#else
         float ack = fe_chain<860>(raw, raw + lag, 0.f);
+#endif
         float d = 0;
         for (int i = lag + 860; i < 864; i++) d = d + raw[i] * raw[i - lag];
         ack += d;
@@ -327,7 +435,12 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
           lag1 = T1; lag2 = T1b;
         }
         float dot1 = 0, dot2 = 0;
+        // x = pbuf + 384 sits at an even float of the (even) slice: the parity of x - lag is the parity of the lag
+#if PN_FP_PAIRS
+        fp_chain2_pairs<480>(x, x - lag1, (lag1 & 1) != 0, x - lag2, (lag2 & 1) != 0, dot1, dot2);
+#else
         fe_chain2<480>(x, x - lag1, x - lag2, dot1, dot2);
+#endif
         const float xx = __shfl(dot1, gb);
         float xy = __shfl(dot1, gb + 1);
         // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, group-uniform.  Squares formed lane-parallel,
@@ -404,8 +517,14 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         }
         best_xy = (0 > best_xy) ? 0 : best_xy;
         if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
-        const float xc = fe_chain<480>(x, x - (Tsel + (l < 3 ? l : 2) - 1), 0.f);
-        const float xc0 = __shfl(xc, gb), xc1 = __shfl(xc, gb + 1), xc2 = __shfl(xc, gb + 2);
+        // xcorr[k] = x . (x - (T + k - 1)), k = 0..2 (pitch.cpp:511-512): lane lam holds k = 2 - lam, so that the operands of
+        // consecutive lanes are consecutive floats (x[j - Tsel - 1 + lam]) and one row read serves 12 steps
+#if PN_FP_ROWS
+        const float xc = fp_chain_rows<480>(x, x - (Tsel + 1), l, 0.f);
+#else
+        const float xc = fe_chain<480>(x, x - (Tsel + 1) + (l < 3 ? l : 2), 0.f);
+#endif
+        const float xc0 = __shfl(xc, gb + 2), xc1 = __shfl(xc, gb + 1), xc2 = __shfl(xc, gb);
         int off2;
         if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
         else if ((xc0 - xc2) > .7f * (xc1 - xc2)) off2 = -1;
