@@ -22,6 +22,7 @@
 // every order-sensitive sum is the reference's sequential chain on one lane.  Bit-identical to the single-launch kernel.
 #define PN_FE_G 4
 #include "pn_dsp_fe_helpers.inc"
+#include <stdlib.h>
 
 #define FP_SPB 16                       // streams per block (4 waves)
 #define FP_THREADS 256
@@ -110,19 +111,28 @@ __device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1,
                                                 float &acc1, float &acc2) {
   constexpr int U = 16, NF = N / U;
   static_assert(N % U == 0 && NF % 2 == 0, "N");
-  const float2 *p1 = reinterpret_cast<const float2 *>(b1 - (o1 ? 1 : 0)), *p2 = reinterpret_cast<const float2 *>(b2 - (o2 ? 1 : 0));
-  float4 a0[4], a1[4]; float2 r0[9], s0[9], r1[9], s1[9];
+  typedef float fp_f2 __attribute__((ext_vector_type(2)));
+  // explicit LDS address space + volatile: each pair stays ONE ds_read_b64 (2 LDS cycles); as plain loads the compiler
+  // either splits them (ds_read2_b32, alignment unproven) or merges two into ds_read2_b64 (8 cycles per two pairs)
+  typedef __attribute__((address_space(3))) const volatile fp_f2 fp_lds_f2;
+  fp_lds_f2 *p1 = (fp_lds_f2 *)(b1 - (o1 ? 1 : 0)), *p2 = (fp_lds_f2 *)(b2 - (o2 ? 1 : 0));
+  // the pairs are unpacked into scalars at once: element u of the lane's run is f[u] or f[u + 1] (ONE v_cndmask per
+  // operand; left as vector lanes the compiler turns the choice into a dynamic vector index = a chain of 16 selects)
+  float4 a0[4], a1[4]; float r0[18], s0[18], r1[18], s1[18];
 #define FP_C2_LOAD(av, rv, sv, blk) do {                                                        \
     _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
-    _Pragma("unroll") for (int u_ = 0; u_ < 9; u_++) { (rv)[u_] = p1[8 * (blk) + u_]; (sv)[u_] = p2[8 * (blk) + u_]; } \
+    _Pragma("unroll") for (int u_ = 0; u_ < 9; u_++) {                                          \
+      const fp_f2 t1_ = p1[8 * (blk) + u_], t2_ = p2[8 * (blk) + u_];                           \
+      (rv)[2 * u_] = t1_.x; (rv)[2 * u_ + 1] = t1_.y; (sv)[2 * u_] = t2_.x; (sv)[2 * u_ + 1] = t2_.y; } \
   } while (0)
-#define FP_C2_AT(rv, o_, u_) ((o_) ? (((u_) & 1) ? (rv)[((u_) + 1) >> 1].x : (rv)[(u_) >> 1].y) : (((u_) & 1) ? (rv)[(u_) >> 1].y : (rv)[(u_) >> 1].x))
 #define FP_C2_MAC(av, rv, sv) do {                                                              \
     _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                          \
       const float ax_[4] = {(av)[v_].x, (av)[v_].y, (av)[v_].z, (av)[v_].w};                    \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; e_++) {                                        \
-        acc1 = acc1 + ax_[e_] * FP_C2_AT(rv, o1, 4 * v_ + e_);                                  \
-        acc2 = acc2 + ax_[e_] * FP_C2_AT(sv, o2, 4 * v_ + e_);                                  \
+        const float y1_ = o1 ? (rv)[4 * v_ + e_ + 1] : (rv)[4 * v_ + e_];                       \
+        const float y2_ = o2 ? (sv)[4 * v_ + e_ + 1] : (sv)[4 * v_ + e_];                       \
+        acc1 = acc1 + ax_[e_] * y1_;                                                            \
+        acc2 = acc2 + ax_[e_] * y2_;                                                            \
       }                                                                                         \
     }                                                                                           \
   } while (0)
@@ -135,7 +145,6 @@ __device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1,
     FP_C2_MAC(a1, r1, s1);
   }
 #undef FP_C2_LOAD
-#undef FP_C2_AT
 #undef FP_C2_MAC
 }
 
@@ -231,12 +240,19 @@ __device__ __forceinline__ float fp_sparse_at(int t, int gb, int cidx, float cva
 
 __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
     int n_streams, int frame_t, const float *__restrict__ hist, float *__restrict__ feat,
-    int *__restrict__ last_period, float *__restrict__ last_gain, float *__restrict__ aux) {
+    int *__restrict__ last_period, float *__restrict__ last_gain, float *__restrict__ aux, int stagger) {
   __shared__ __attribute__((aligned(16))) float SH[FP_SPB * FP_SLICE];
   const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid >> 6;
   const int sub = lane / L, l = lane % L, gb = sub * L;
   const int slice0 = (wave * G + sub) * FP_SLICE;
   const int base_slot0 = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
+
+  // Every wave runs the same sequence of VALU-heavy (decimated correlation) and LDS-heavy (remove_doubling) phases, and
+  // all waves of a launch start together: left alone they load the VALUs and then the LDS pipe in unison.  Waves 2 and 3
+  // of every block start `stagger` sleep quanta (of 127 x 64 cycles) late, so that half of a CU's waves are in the other
+  // kind of phase.  No barrier follows: the waves of a block never exchange data.
+  if (wave >= 2)
+    for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(127);
 
   for (int s0 = (blockIdx.x * (FP_SPB / G) + wave) * G; s0 < n_streams; s0 += gridDim.x * FP_SPB) {
     const int s = s0 + sub;
@@ -550,6 +566,8 @@ void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const floa
   const int need = (n_streams + FP_SPB - 1) / FP_SPB;
   const int cap = 256 * 2;                               // two LDS-resident blocks on each of 256 CUs
   const int grid = need < cap ? need : cap;
+  static const int stagger = getenv("PERCEPNET_FP_STAGGER") ? atoi(getenv("PERCEPNET_FP_STAGGER")) : 0;
+  // only worth it when a block walks several stream groups (the delay is paid once per launch)
   hipLaunchKernelGGL(pn_fe_pitch_kernel, dim3(grid), dim3(FP_THREADS), 0, st, n_streams, (int)(frame % PN_HIST_FRAMES), hist,
-                     feat, last_period, last_gain, aux);
+                     feat, last_period, last_gain, aux, need >= 4 * cap ? stagger : 0);
 }
