@@ -87,6 +87,10 @@ struct NnShared {
   float A[2][BM][LDT];       // 2 x 18432 B   double-buffered K-tiles
   float B[2][4 * 32][LDT];   // 2 x 18432 B   (up to 4 column tiles: dense NT<=4, GRU 3 gates)
   float tansig[208];
+#ifdef PN_NN_LDS_PAD
+  char pad[PN_NN_LDS_PAD];   // experiment (tools/gpu_overlap.sh): > 7.3 KB caps these kernels at ONE block per CU, leaving
+                             // 81 KB of LDS and 264 registers per lane for a DSP block of another half-batch
+#endif
 };
 
 // ---- software-pipelined staging: global -> registers (issued before the MFMAs of the current
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
     float *__restrict__ h_new, int n_rows, int n_mtiles) {
   __shared__ NnShared S;
+#ifdef PN_NN_SETPRIO
+  __builtin_amdgcn_s_setprio(PN_NN_SETPRIO);   // experiment: the MFMA waves win every issue arbitration against co-resident DSP waves
+#endif
   const int NTn = N >> 5;
   int mt, nt;
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
@@ -366,6 +373,9 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
     PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
     const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
   __shared__ NnShared S;
+#ifdef PN_NN_SETPRIO
+  __builtin_amdgcn_s_setprio(PN_NN_SETPRIO);   // experiment: the MFMA waves win every issue arbitration against co-resident DSP waves
+#endif
   int mt, cb;
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

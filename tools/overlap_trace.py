@@ -2,7 +2,7 @@
 of the other stream.  usage: overlap_trace.py <kernel_trace.csv>"""
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith(("pn_", "void pn_"))]
-ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], "fe" if "frontend" in r["Kernel_Name"] else ("be" if "backend" in r["Kernel_Name"] else "nn")) for r in rows]
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], "fe" if ("frontend" in r["Kernel_Name"] or "pn_fe_" in r["Kernel_Name"]) else ("be" if "backend" in r["Kernel_Name"] else "nn")) for r in rows]
 ev.sort()
 t0 = ev[len(ev) // 2][0]
 tot_fe = ov = 0
@@ -14,5 +14,6 @@ for s, e, st, k in ev:
             ov += min(e, e2) - max(s, s2)
 print(f"front-end kernel time {tot_fe/1e6:.2f} ms, of which concurrent with another stream's network kernels: {ov/1e6:.2f} ms ({100*ov/max(tot_fe,1):.0f} %)")
 # a short timeline
-for s, e, st, k in [x for x in ev if x[0] >= t0][:40]:
-    print(f"  {(s-t0)/1e3:9.1f} us  +{(e-s)/1e3:8.1f} us  stream {st}  {k}")
+names = {(int(r["Start_Timestamp"]), r["Stream_Id"]): r["Kernel_Name"].replace("void ", "").split("(")[0][:28] for r in rows}
+for s, e, st, k in [x for x in ev if x[0] >= t0][:60]:
+    print(f"  {(s-t0)/1e3:9.1f} us  +{(e-s)/1e3:8.1f} us  stream {st}  {k}  {names.get((s, st), '')}")
