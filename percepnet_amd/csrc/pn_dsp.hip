@@ -2,14 +2,19 @@
 // pitch-filter mix, band-gain interpolation, inverse transform, window, overlap-add, PCM conversion
 //   == pitch_filter + gain apply + frame_synthesis (reference denoise.cpp:436-485, 539-545) + the
 //      CLI's float->short (main.cpp:36).
-// (The front end — features, pitch, FFTs of the analysis side — is pn_dsp_fe.hip.)
+// (The front end — features, pitch, FFTs of the analysis side — is pn_dsp_fe_split_*.hip / pn_dsp_fe.hip.)
 //
 // Numerics contract: every arithmetic step is the reference's operation in the reference's order
 // with separate IEEE binary32 rounding (-ffp-contract=off), so given identical g/r the synthesis
-// is bit-identical to the CPU reference.  512-thread blocks = 8 wavefronts = 8 concurrent streams;
-// the block stages the shared tables into LDS once; each wave owns a private FFT buffer and loops
-// over streams; no block-level barrier after the staging (PN_WAVE_SYNC is a compiler fence).
-#include "pn_common.h"
+// is bit-identical to the CPU reference.  512-thread blocks = 8 wavefronts = 8 concurrent streams, two blocks per CU.
+//
+// Round 3: the inverse transform (a forward 960-point FFT of the Hermitian-extended, conjugated spectrum read out in
+// reverse, denoise.cpp:306-323) runs as the three register-fused passes of pn_fft960.h instead of a digit-reversal
+// scatter + five in-place LDS stages (60 % of this kernel's LDS cycles were bank conflicts): lane l < 60 forms the 16
+// inputs 4l + c + 240k of its four first-stage butterflies directly from the 400-bin spectra (pitch filter, gain,
+// conjugate, 1/960), and the last pass leaves the 960 real outputs in registers, from where window, overlap-add and the
+// PCM cast write straight to HBM.
+#include "pn_fft960.h"
 
 #define LANES 64
 #ifndef PN_DSP_WPB
@@ -21,140 +26,19 @@
 #define WPB PN_DSP_WPB
 #define DSP_THREADS (LANES * WPB)
 
-// same-wave LDS producer -> consumer ordering
-#define PN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 // same-wave global-memory store -> load ordering (drains vmcnt)
 #define PN_WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-struct alignas(16) PnDspTablesLds {
-  float2 tw[PN_NFFT];            // 7680 B
-  float win[PN_FRAME];           // 1920 B
-  float frac[PN_SPEC_BINS];      // 1600 B
-  int16_t bitrev[PN_NFFT];       // 1920 B
-  int16_t border[PN_NB + 2];
-  uint8_t band[PN_SPEC_BINS];
-  float comb_w[8];
-};
 struct alignas(16) PnDspWaveLds {
-  float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
-  float e[4][PN_NB + 2];         // 576 B
+  float2 fft[FS_NF];             // 8160 B  FFT work buffer (layout phi)
+  float e[4][PN_NB + 2];         // g | r | 1 - r | Ex (post-filter)
 };
 struct PnDspShared {
-  PnDspTablesLds t;
+  float win[PN_FRAME];           // 1920 B
+  float frac[PN_SPEC_BINS];      // 1600 B
+  uint8_t band[PN_SPEC_BINS];
   PnDspWaveLds w[WPB];
 };
-
-__device__ __forceinline__ void pn_stage_tables(PnDspTablesLds &S, const PnTables *__restrict__ T) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < PN_NFFT; i += DSP_THREADS) {
-    S.tw[i] = make_float2(T->tw[2 * i], T->tw[2 * i + 1]);
-    S.bitrev[i] = T->bitrev[i];
-  }
-  for (int i = tid; i < PN_FRAME; i += DSP_THREADS) S.win[i] = T->half_window[i];
-  for (int i = tid; i < PN_SPEC_BINS; i += DSP_THREADS) { S.frac[i] = T->bin_frac[i]; S.band[i] = T->bin_band[i]; }
-  if (tid < PN_NB + 2) S.border[tid] = T->border[tid];
-  if (tid < 8) S.comb_w[tid] = T->comb_hann[tid];
-  __syncthreads();
-}
-
-// ---- 960-point FFT in LDS (opus_fft_impl, kiss_fft.cpp:518-564, factors 5,3,4,4,4) -----------
-// Input must already be scaled by 1/960 and digit-reverse scattered (opus_fft_c 578-585).
-
-#define CMUL(m, a, b) do { (m).x = (a).x*(b).x - (a).y*(b).y; (m).y = (a).x*(b).y + (a).y*(b).x; } while (0)
-
-__device__ __forceinline__ void pn_fft960_lds(float2 *F, const float2 *tw, int lane) {
-  PN_WAVE_SYNC();
-  // radix-4, m=1 (degenerate twiddle-free butterfly, kiss_fft.cpp:112-131)
-  for (int b = lane; b < 240; b += LANES) {
-    float2 *f = F + 4 * b;
-    float2 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], s0, s1;
-    s0.x = f0.x - f2.x; s0.y = f0.y - f2.y;
-    f0.x += f2.x; f0.y += f2.y;
-    s1.x = f1.x + f3.x; s1.y = f1.y + f3.y;
-    f2.x = f0.x - s1.x; f2.y = f0.y - s1.y;
-    f0.x += s1.x; f0.y += s1.y;
-    s1.x = f1.x - f3.x; s1.y = f1.y - f3.y;
-    f1.x = s0.x + s1.y; f1.y = s0.y - s1.x;
-    f3.x = s0.x - s1.y; f3.y = s0.y + s1.x;
-    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3;
-  }
-  PN_WAVE_SYNC();
-  // radix-4, m=4 (fstride 60, mm 16) then m=16 (fstride 15, mm 64)  (kiss_fft.cpp:139-166)
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int m = pass ? 16 : 4, fs = pass ? 15 : 60, mm = pass ? 64 : 16;
-    for (int b = lane; b < 240; b += LANES) {
-      const int i = b / m, j = b % m;
-      float2 *f = F + i * mm + j;
-      float2 f0 = f[0], fm = f[m], f2m = f[2 * m], f3m = f[3 * m];
-      const float2 t1 = tw[j * fs], t2 = tw[2 * j * fs], t3 = tw[3 * j * fs];
-      float2 s0, s1, s2, s3, s4, s5;
-      CMUL(s0, fm, t1); CMUL(s1, f2m, t2); CMUL(s2, f3m, t3);
-      s5.x = f0.x - s1.x; s5.y = f0.y - s1.y;
-      f0.x += s1.x; f0.y += s1.y;
-      s3.x = s0.x + s2.x; s3.y = s0.y + s2.y;
-      s4.x = s0.x - s2.x; s4.y = s0.y - s2.y;
-      f2m.x = f0.x - s3.x; f2m.y = f0.y - s3.y;
-      f0.x += s3.x; f0.y += s3.y;
-      fm.x = s5.x + s4.y; fm.y = s5.y - s4.x;
-      f3m.x = s5.x - s4.y; f3m.y = s5.y + s4.x;
-      f[0] = f0; f[m] = fm; f[2 * m] = f2m; f[3 * m] = f3m;
-    }
-    PN_WAVE_SYNC();
-  }
-  // radix-3, m=64, fstride 5, mm 192 (kiss_fft.cpp:196-227); epi3 = tw[fstride*m]
-  {
-    const float epi3 = tw[320].y;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int j = lane;
-      float2 *f = F + i * 192 + j;
-      float2 f0 = f[0], fm = f[64], f2m = f[128], s0, s1, s2, s3;
-      CMUL(s1, fm, tw[j * 5]); CMUL(s2, f2m, tw[2 * j * 5]);
-      s3.x = s1.x + s2.x; s3.y = s1.y + s2.y;
-      s0.x = s1.x - s2.x; s0.y = s1.y - s2.y;
-      fm.x = f0.x - s3.x * .5f; fm.y = f0.y - s3.y * .5f;
-      s0.x *= epi3; s0.y *= epi3;
-      f0.x += s3.x; f0.y += s3.y;
-      f2m.x = fm.x + s0.y; f2m.y = fm.y - s0.x;
-      fm.x = fm.x - s0.y; fm.y = fm.y + s0.x;
-      f[0] = f0; f[64] = fm; f[128] = f2m;
-    }
-    PN_WAVE_SYNC();
-  }
-  // radix-5, m=192, fstride 1 (kiss_fft.cpp:259-304); ya = tw[m], yb = tw[2m]
-  {
-    const float2 ya = tw[192], yb = tw[384];
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-      const int u = lane + LANES * it;
-      float2 *f = F + u;
-      float2 f0 = f[0], f1 = f[192], f2 = f[384], f3 = f[576], f4 = f[768];
-      float2 s0 = f0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
-      CMUL(s1, f1, tw[u]); CMUL(s2, f2, tw[2 * u]); CMUL(s3, f3, tw[3 * u]); CMUL(s4, f4, tw[4 * u]);
-      s7.x = s1.x + s4.x; s7.y = s1.y + s4.y;
-      s10.x = s1.x - s4.x; s10.y = s1.y - s4.y;
-      s8.x = s2.x + s3.x; s8.y = s2.y + s3.y;
-      s9.x = s2.x - s3.x; s9.y = s2.y - s3.y;
-      f0.x = f0.x + (s7.x + s8.x);
-      f0.y = f0.y + (s7.y + s8.y);
-      s5.x = s0.x + (s7.x * ya.x + s8.x * yb.x);
-      s5.y = s0.y + (s7.y * ya.x + s8.y * yb.x);
-      s6.x = s10.y * ya.y + s9.y * yb.y;
-      s6.y = -(s10.x * ya.y + s9.x * yb.y);
-      f1.x = s5.x - s6.x; f1.y = s5.y - s6.y;
-      f4.x = s5.x + s6.x; f4.y = s5.y + s6.y;
-      s11.x = s0.x + (s7.x * yb.x + s8.x * ya.x);
-      s11.y = s0.y + (s7.y * yb.x + s8.y * ya.x);
-      s12.x = s9.y * ya.y - s10.y * yb.y;
-      s12.y = s10.x * yb.y - s9.x * ya.y;
-      f2.x = s11.x + s12.x; f2.y = s11.y + s12.y;
-      f3.x = s11.x - s12.x; f3.y = s11.y - s12.y;
-      f[0] = f0; f[192] = f1; f[384] = f2; f[576] = f3; f[768] = f4;
-    }
-    PN_WAVE_SYNC();
-  }
-}
 
 // float -> int16 as the reference CLI's x86-64 build does it (main.cpp:36): truncate toward zero
 // to int32 (cvttss2si; NaN / out of range -> 0x80000000), keep the low 16 bits.
@@ -175,20 +59,16 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
     float *__restrict__ synth_mem,         // [n_streams][480]
     TOut *__restrict__ out) {              // [n_streams][480]
   __shared__ PnDspShared SH;
-  const int lane = threadIdx.x & (LANES - 1), wave = threadIdx.x >> 6;
-  pn_stage_tables(SH.t, T);
-  const PnDspTablesLds &S = SH.t;
+  const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < PN_FRAME; i += DSP_THREADS) SH.win[i] = T->half_window[i];
+  for (int i = tid; i < PN_SPEC_BINS; i += DSP_THREADS) { SH.frac[i] = T->bin_frac[i]; SH.band[i] = T->bin_band[i]; }
+  __syncthreads();
   PnDspWaveLds &W = SH.w[wave];
+  FsLane Z;
+  fs_lane_init(Z, T, lane);
   const float scale = 1.f / PN_NFFT;
+  const int lc = lane < 60 ? lane : 59;
   for (int s = blockIdx.x * WPB + wave; s < n_streams; s += gridDim.x * WPB) {
-    // global operands are read in batches ahead of their use (a load waited for inside the loop costs its full
-    // latency every iteration); three batches of five keep the kernel at 4 waves per SIMD without spills
-    float smv[(PN_FRAME + LANES - 1) / LANES];
-#pragma unroll
-    for (int it = 0; it < (PN_FRAME + LANES - 1) / LANES; it++) {
-      const int i = lane + LANES * it;
-      smv[it] = synth_mem[(size_t)s * PN_FRAME + (i < PN_FRAME ? i : 0)];
-    }
     const bool sil = silence[s] != 0;
     if (lane < PN_NB) {
       const float g = gr[(size_t)s * 68 + lane], r = gr[(size_t)s * 68 + PN_NB + lane];
@@ -201,7 +81,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
       // order (231-238), one global factor (241-244).  Every lane runs the 34-term chains redundantly on
       // LDS broadcasts; sinf is OCML's here and libm's in the reference (both within 1 ULP of sin).
       float gw = 0.f;
-      float *gws = reinterpret_cast<float *>(W.fft);          // the FFT buffer is free until the scatter below
+      float *gws = reinterpret_cast<float *>(W.fft);          // the FFT buffer is free until P1 below
       if (lane < PN_NB) { const float g = W.e[0][lane]; gw = g * sinf((float)(M_PI / 2 * (double)g)); gws[lane] = gw; }
       PN_WAVE_SYNC();
       float E0 = 0.f, E1 = 0.f;
@@ -217,34 +97,34 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
       if (lane < PN_NB) W.e[0][lane] = G * gw;
       PN_WAVE_SYNC();
     }
-    // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian
-    // extension + scale + digit-reverse scatter of inverse_transform (306-317).  Bins >= 400
-    // are exactly 0 (interp_band_gain never writes them).
+    // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian extension + 1/960 of
+    // inverse_transform (306-317).  Input i of the transform is bin k = i (i <= 480) or 960 - i (conjugated); bins >= 400
+    // are exactly 0 (interp_band_gain never writes them).  Lane l < 60, butterfly c, input j: i = 4l + c + 240j.
+    if (lane < 60) {
+      const float2 *Xs = Xspec + (size_t)s * PN_SPEC_BINS, *Ps = Pspec + (size_t)s * PN_SPEC_BINS;
 #pragma unroll 1
-    for (int h0 = 0; h0 < 15; h0 += 5) {
-      float2 xv[5], pv[5];
+      for (int c = 0; c < 4; c++) {
+        float2 xv[4], pv[4];
+        int kk[4];
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        if (h0 + u < 15) {
-          const int i = lane + LANES * (h0 + u);
-          const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
-          const int kc = k < PN_SPEC_BINS ? k : PN_SPEC_BINS - 1;
-          xv[u] = Xspec[(size_t)s * PN_SPEC_BINS + kc];
-          pv[u] = Pspec[(size_t)s * PN_SPEC_BINS + kc];
+        for (int j = 0; j < 4; j++) {
+          const int i = 4 * lc + c + 240 * j;
+          kk[j] = (i <= PN_FRAME) ? i : PN_WINDOW - i;
+          const int kc = kk[j] < PN_SPEC_BINS ? kk[j] : PN_SPEC_BINS - 1;
+          xv[j] = Xs[kc];
+          pv[j] = Ps[kc];
         }
-      }
+        float2 f[4];
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        if (h0 + u < 15) {
-          const int i = lane + LANES * (h0 + u);
-          const int k = (i <= PN_FRAME) ? i : PN_WINDOW - i;
+        for (int j = 0; j < 4; j++) {
+          const int i = 4 * lc + c + 240 * j;
           float2 x = make_float2(0.f, 0.f);
-          if (k < PN_SPEC_BINS) {
-            x = xv[u];
-            const int b = S.band[k];
-            const float fr = S.frac[k];
+          if (kk[j] < PN_SPEC_BINS) {
+            x = xv[j];
+            const int b = SH.band[kk[j]];
+            const float fr = SH.frac[kk[j]];
             if (!sil) {
-              const float2 p = pv[u];
+              const float2 p = pv[j];
               const float rf1 = (1 - fr) * W.e[2][b] + fr * W.e[2][b + 1];
               x.x = rf1 * x.x; x.y = rf1 * x.y;
               const float rf2 = (1 - fr) * W.e[1][b] + fr * W.e[1][b + 1];
@@ -254,24 +134,40 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
             x.x *= gf; x.y *= gf;
           }
           if (i > PN_FRAME) x.y = -x.y;
-          W.fft[S.bitrev[i]] = make_float2(scale * x.x, scale * x.y);
+          f[j] = make_float2(scale * x.x, scale * x.y);
         }
+        fs_bfly4_m1(f);
+        const int off = c == 0 ? Z.p1off[0] : (c == 1 ? Z.p1off[1] : (c == 2 ? Z.p1off[2] : Z.p1off[3]));
+        float4 *dst = reinterpret_cast<float4 *>(W.fft + off);
+        dst[0] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+        dst[1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
       }
     }
-    pn_fft960_lds(W.fft, S.tw, lane);
-    // reversed read-out x960 (318-323), window, overlap-add (352-359)
+    float2 w[3][5];
+    fs_fft_p23<true>(W.fft, T, lane, w);
+    // reversed read-out x960 (318-323), window, overlap-add (352-359): output p = u + 64b + 192c of the transform is
+    //   p == 0 or p >= 481: time sample i = (960 - p) % 960 of the first half  -> out[i] = 960*re * win[i] + synth_mem[i]
+    //   1 <= p <= 480:      time sample 480 + i, i = 480 - p, of the second half -> synth_mem[i] = 960*re * win[479 - i]
     float *sm = synth_mem + (size_t)s * PN_FRAME;
+    float smv[15];
 #pragma unroll
-    for (int it = 0; it < (PN_FRAME + LANES - 1) / LANES; it++) {
-      const int i = lane + LANES * it;
-      if (i < PN_FRAME) {
-        const float t_lo = (PN_WINDOW * W.fft[i == 0 ? 0 : PN_WINDOW - i].x) * S.win[i];
-        const int i2 = PN_FRAME + i;                       // second half, window index 959 - i2
-        const float t_hi = (PN_WINDOW * W.fft[PN_WINDOW - i2].x) * S.win[PN_WINDOW - 1 - i2];
-        const float o = t_lo + smv[it];
-        sm[i] = t_hi;
+    for (int q = 0; q < 15; q++) {
+      const int p = lane + 64 * (q % 3) + 192 * (q / 3);
+      const bool lo = p == 0 || p > PN_FRAME;
+      smv[q] = lo ? sm[p == 0 ? 0 : PN_WINDOW - p] : 0.f;
+    }
+    PN_WAVE_SYNC_GLOBAL();                     // the loads above are this stream's old overlap memory: read before it is rewritten
+#pragma unroll
+    for (int q = 0; q < 15; q++) {
+      const int p = lane + 64 * (q % 3) + 192 * (q / 3);
+      const float re = w[q % 3][q / 3].x;
+      if (p == 0 || p > PN_FRAME) {
+        const int i = p == 0 ? 0 : PN_WINDOW - p;
+        const float o = (PN_WINDOW * re) * SH.win[i] + smv[q];
         if (sizeof(TOut) == 2) out[(size_t)s * PN_FRAME + i] = (TOut)pn_f2s(o * 32768);
         else out[(size_t)s * PN_FRAME + i] = (TOut)o;
+      } else {
+        sm[PN_FRAME - p] = (PN_WINDOW * re) * SH.win[p - 1];
       }
     }
     PN_WAVE_SYNC();
