@@ -33,9 +33,47 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-# The kernels carry two workarounds for codegen hazards of this exact toolchain; a different
-# hipcc is allowed but announced, and the context-creation self-test (pn_ctx_create) is what guards the results.
+# The kernels were validated with this toolchain (the MFMA wait-state rule is met by the compiler's own
+# padding, with zero margin); a different hipcc is allowed but announced, and the create-time self-tests of the network
+# and DSP kernels (pn_ctx_create) are what guard the results.
 EXPECTED_HIP = "7.2"
+
+# Register hygiene gate for the PRODUCTION DSP kernels: the single-launch front end of rounds 1-2 ran at 256 VGPRs + 219
+# AGPR spill copies, the regime in which a register-allocation-dependent corruption once appeared.  The
+# phase-split kernels and the back end must stay free of AGPR spill copies and (almost) free of scratch; the build fails
+# otherwise.  kernel-name prefix -> (max AGPRs, max scratch bytes per lane)
+RESOURCE_LIMITS = {"pn_fe_spec_in_kernel": (0, 0), "pn_fe_spec_out_kernel": (0, 32), "pn_fe_pitch_kernel": (0, 48),
+                   "pn_backend_kernel": (0, 64)}
+RESOURCE_SOURCES = ("pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip")
+
+
+def parse_resource_remarks(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage stderr -> {demangled-ish kernel name: {"VGPRs": n, "AGPRs": n, ...}}"""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: .*Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            mm = re.match(r"_Z\d+(pn_[a-z0-9_]+)", name)
+            cur = out.setdefault(name, {"kernel": mm.group(1) if mm else name})
+            continue
+        m = re.search(r"remark: .*?\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    return out
+
+
+def check_resources(remarks):
+    """-> list of violations of RESOURCE_LIMITS (empty = clean)."""
+    bad = []
+    for name, r in remarks.items():
+        for prefix, (max_agpr, max_scratch) in RESOURCE_LIMITS.items():
+            if r["kernel"].startswith(prefix):
+                if r.get("AGPRs", 0) > max_agpr or r.get("ScratchSize", 0) > max_scratch:
+                    bad.append(f"{r['kernel']}: {r.get('VGPRs')} VGPRs, {r.get('AGPRs')} AGPRs, {r.get('ScratchSize')} B/lane scratch "
+                               f"(limits: {max_agpr} AGPRs, {max_scratch} B) [{name}]")
+    return bad
 
 
 def toolchain_info(hipcc):
@@ -89,15 +127,31 @@ def build(force=False, verbose=True):
         os.path.join(HERE, "..", "include", "percepnet_hip.h"),
         os.path.join(HERE, "..", "include", "percepnet_nnet_data.h")]
     objs = []
+    resources = {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
-        if force or _stale(o, deps):
+        rlog = o + ".resources.txt"
+        if force or _stale(o, deps) or (src in RESOURCE_SOURCES and not os.path.exists(rlog)):
             cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            if src in RESOURCE_SOURCES:
+                cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            if src in RESOURCE_SOURCES:
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode:
+                    sys.stderr.write(r.stderr)
+                    raise subprocess.CalledProcessError(r.returncode, cmd)
+                open(rlog, "w").write("\n".join(l for l in r.stderr.splitlines() if "remark:" in l) + "\n")
+            else:
+                subprocess.check_call(cmd)
+        if src in RESOURCE_SOURCES and os.path.exists(rlog):
+            resources.update(parse_resource_remarks(open(rlog).read()))
         objs.append(o)
+    bad = check_resources(resources)
+    if bad:
+        raise RuntimeError("register hygiene gate (build.RESOURCE_LIMITS) failed:\n  " + "\n  ".join(bad))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
@@ -123,6 +177,10 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
     with open(os.path.join(LIBDIR, "BUILD_INFO.txt"), "w") as f:
         f.write(toolchain_info(hipcc) + "\nflags: " + " ".join(FLAGS) + "\n")
+        f.write("DSP kernel resources (hipcc -Rpass-analysis=kernel-resource-usage):\n")
+        for name, r in sorted(resources.items(), key=lambda kv: kv[1]["kernel"]):
+            f.write(f"  {r['kernel']}: VGPRs {r.get('VGPRs')} AGPRs {r.get('AGPRs')} scratch {r.get('ScratchSize')} B/lane "
+                    f"LDS {r.get('LDS Size')} B/block occupancy {r.get('Occupancy')} waves/SIMD  [{name[:60]}]\n")
     return LIB
 
 

@@ -15,6 +15,9 @@
 #include <vector>
 
 #include "pn_launch.h"
+#include "pn_selftest_golden.h"
+
+int g_pn_dsp_grid_cap = 0;
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -241,6 +244,7 @@ static int pn_fe_mode_for(int n_streams) {
   return FE_SPLIT;      // measured: 0.102 vs 0.124 ms (g2) at 1024 streams, 0.130 vs 0.166 (g4) at 4096, 1.32 vs 2.37 at 65536 (profiles/r03e_*)
 }
 static int nn_selftest(pn_ctx *c);
+static int dsp_selftest(pn_ctx *c);
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
                           int force_small, int force_small_gru);
 
@@ -366,6 +370,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
   if (selftest && nn_mode != PN_NN_STRICT && nn_selftest(c)) goto fail;
+  if (selftest && dsp_selftest(c)) goto fail;
   return c;
 fail:
   pn_ctx_destroy(c);
@@ -601,6 +606,80 @@ static int nn_selftest(pn_ctx *c) {
     return -1;
   }
   g_selftest_done[key] = 0;
+  return 0;
+}
+
+
+// Known-answer self-test of the DSP kernels, the counterpart of nn_selftest (PERCEPNET_SELFTEST=0 skips both).
+// The first context of every (device, front-end family) in a process runs a fixed integer-generated waveform
+// (two triangle waves + LCG noise, quiet and clipping stretches) through a temporary 40-stream context whose DSP
+// launches are capped at ONE block (g_pn_dsp_grid_cap): every stream is fed the same PCM, so the 40 streams of 3 to 10
+// grid-stride rounds must agree with each other word for word, the silence flags of all 14 frames (a full wrap of
+// the 12-frame history ring) and the 70 features of the last frame must equal the CPU oracle's bit patterns stored in
+// pn_selftest_golden.h (tools/make_dsp_selftest_golden.py; the features never touch the network).
+static void selftest_pcm(std::vector<int16_t> &out) {     // in step with tools/make_dsp_selftest_golden.py
+  const int n = PN_SELFTEST_FRAMES * PN_FRAME;
+  out.resize(n);
+  uint32_t x = 2463534242u;
+  for (int i = 0; i < n; i++) {
+    const int p1 = (i * 7) % 960, t1 = p1 < 480 ? p1 - 480 : 1440 - p1 - 480;
+    const int p2 = (i * 31) % 960, t2 = p2 < 480 ? p2 - 480 : 1440 - p2 - 480;
+    x = x * 1664525u + 1013904223u;
+    const int noise = (int)((x >> 16) % 2001u) - 1000;
+    const int amp = (i / 2400) % 2 == 1 ? 200 : 24;
+    int v = amp * t1 + (amp / 3) * t2 + noise;
+    v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+    out[i] = (int16_t)v;
+  }
+}
+
+static int dsp_selftest(pn_ctx *c) {
+  const char *env = getenv("PERCEPNET_SELFTEST");
+  if (env && !atoi(env)) return 0;
+  static std::map<std::pair<int, int>, int> done;
+  const auto key = std::make_pair(c->device, c->fe_mode);
+  std::lock_guard<std::mutex> lk(g_selftest_mu);
+  if (done.count(key)) return 0;
+  const int Bt = 40;
+  std::vector<int16_t> pcm;
+  selftest_pcm(pcm);
+  pn_model *m = selftest_model();
+  g_last_alloc_oom = false;
+  pn_ctx *t = m ? ctx_create(m, c->device, Bt, PN_NN_MFMA, NULL, false, -1, -1) : NULL;
+  if (!t) {
+    const bool oom = g_last_alloc_oom;
+    pn_model_free(m);
+    if (oom) { fprintf(stderr, "percepnet_hip: DSP self-test SKIPPED on device %d (no memory for its temporaries)\n", c->device); done[key] = 1; return 0; }
+    std::string why = pn_last_error(); pn_set_error("DSP self-test could not run: %s", why.c_str()); return -1;
+  }
+  std::vector<int16_t> in((size_t)Bt * PN_FRAME), out((size_t)Bt * PN_FRAME);
+  std::vector<float> feat((size_t)Bt * PN_NFEAT);
+  std::vector<int32_t> sil(Bt);
+  int rc = 0; std::string msg;
+  g_pn_dsp_grid_cap = 1;
+  for (int f = 0; f < PN_SELFTEST_FRAMES && !rc; f++) {
+    for (int s = 0; s < Bt; s++) memcpy(&in[(size_t)s * PN_FRAME], &pcm[(size_t)f * PN_FRAME], PN_FRAME * sizeof(int16_t));
+    if (pn_process_host_i16(t, in.data(), out.data(), NULL) || pn_ctx_read_features(t, feat.data(), sil.data())) { rc = -1; msg = pn_last_error(); break; }
+    for (int s = 0; s < Bt && !rc; s++) {
+      if (sil[s] != kSelftestSilence[f]) { rc = -2; msg = "silence flag of frame " + std::to_string(f) + ", stream " + std::to_string(s); }
+      if (memcmp(&feat[(size_t)s * PN_NFEAT], &feat[0], PN_NFEAT * 4)) { rc = -2; msg = "stream " + std::to_string(s) + " differs from stream 0 at frame " + std::to_string(f) + " (same input)"; }
+    }
+    if (!rc && f == PN_SELFTEST_FRAMES - 1)
+      for (int k = 0; k < PN_NFEAT; k++) {
+        uint32_t w; memcpy(&w, &feat[k], 4);
+        if (w != kSelftestFeat[k]) { rc = -2; msg = "feature " + std::to_string(k) + " of the last frame"; break; }
+      }
+  }
+  g_pn_dsp_grid_cap = 0;
+  pn_ctx_destroy(t); pn_model_free(m);
+  if (env && atoi(env) >= 2) fprintf(stderr, "percepnet_hip: DSP self-test device %d front end %d: %s\n", c->device, c->fe_mode, rc ? msg.c_str() : "70 features + 14 silence flags bit-equal to the CPU oracle, 40 streams identical");
+  if (rc == -1) { pn_set_error("DSP self-test could not run: %s", msg.c_str()); return -1; }
+  if (rc) {
+    pn_set_error("DSP self-test FAILED (front end %s): %s does not match the CPU reference's known answer — this build of the DSP "
+                 "kernels is not bit-exact (DESIGN.md 4.4); refusing to run", c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"), msg.c_str());
+    return -1;
+  }
+  done[key] = 0;
   return 0;
 }
 

@@ -15,6 +15,7 @@
 // conjugate, 1/960), and the last pass leaves the 960 real outputs in registers, from where window, overlap-add and the
 // PCM cast write straight to HBM.
 #include "pn_fft960.h"
+#include "pn_launch.h"
 
 #define LANES 64
 #ifndef PN_DSP_WPB
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
 static inline int pn_dsp_grid(int n_streams, int blocks_per_cu) {
   const int need = (n_streams + WPB - 1) / WPB;
   const int full = PN_DSP_WAVES_PER_SIMD * 4 / WPB;
-  const int cap = 256 * ((blocks_per_cu > 0 && blocks_per_cu < full) ? blocks_per_cu : full);
+  const int cap = g_pn_dsp_grid_cap > 0 ? g_pn_dsp_grid_cap : 256 * ((blocks_per_cu > 0 && blocks_per_cu < full) ? blocks_per_cu : full);
   return need < cap ? need : cap;
 }
 

@@ -33,6 +33,7 @@
 // groups never exchange data, LDS operations of one wave execute in order, PN_WAVE_SYNC is a
 // compiler fence.
 #include "pn_dsp_fe_helpers.inc"
+#include "pn_launch.h"
 
 struct alignas(16) FeStreamLds {
   float2 fft[PN_NFFT];           // 7680 B  FFT work buffer; pitch scratch / per-bin products alias it
@@ -559,7 +560,8 @@ void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_
                         float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
   const int need = (n_streams + FE_SPB - 1) / FE_SPB;
   const int cap = 256 * (16 / FE_SPB);                 // LDS-resident blocks on 256 CUs
-  const int grid = need < cap ? need : cap;            // grid-stride
+  int grid = need < cap ? need : cap;                  // grid-stride
+  if (g_pn_dsp_grid_cap > 0 && grid > g_pn_dsp_grid_cap) grid = g_pn_dsp_grid_cap;
   const int frame_t = (int)(frame % PN_HIST_FRAMES);
   const int slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
   if (in_is_i16)

@@ -23,6 +23,7 @@
 #define PN_FE_G 4
 #include "pn_dsp_fe_helpers.inc"
 #include <stdlib.h>
+#include "pn_launch.h"
 
 #define FP_SPB 16                       // streams per block (4 waves)
 #define FP_THREADS 256
@@ -565,7 +566,8 @@ void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const floa
                         float *last_gain, float *aux) {
   const int need = (n_streams + FP_SPB - 1) / FP_SPB;
   const int cap = 256 * 2;                               // two LDS-resident blocks on each of 256 CUs
-  const int grid = need < cap ? need : cap;
+  int grid = need < cap ? need : cap;
+  if (g_pn_dsp_grid_cap > 0 && grid > g_pn_dsp_grid_cap) grid = g_pn_dsp_grid_cap;
   static const int stagger = getenv("PERCEPNET_FP_STAGGER") ? atoi(getenv("PERCEPNET_FP_STAGGER")) : 0;
   // only worth it when a block walks several stream groups (the delay is paid once per launch)
   hipLaunchKernelGGL(pn_fe_pitch_kernel, dim3(grid), dim3(FP_THREADS), 0, st, n_streams, (int)(frame % PN_HIST_FRAMES), hist,

@@ -35,6 +35,7 @@
 #define FS_WPB 4                        // waves (= concurrent streams) per block
 #define FS_THREADS (LANES * FS_WPB)
 #include "pn_fft960.h"
+#include "pn_launch.h"
 
 #ifndef PN_FS_WAVES_IN
 #define PN_FS_WAVES_IN 4                // waves per SIMD the register budget of spec_in is cut for (4: 128 registers)
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
 // ---- launchers --------------------------------------------------------------------------------------------------------
 static int fs_grid(int n_streams, int blocks_per_cu) {
   const int need = (n_streams + FS_WPB - 1) / FS_WPB;
-  const int cap = 256 * blocks_per_cu;                   // resident 4-wave blocks on 256 CUs
+  const int cap = g_pn_dsp_grid_cap > 0 ? g_pn_dsp_grid_cap : 256 * blocks_per_cu;   // resident 4-wave blocks on 256 CUs
   return need < cap ? need : cap;
 }
 void pn_launch_fe_spec_in(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,

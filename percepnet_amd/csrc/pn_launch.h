@@ -2,6 +2,11 @@
 #pragma once
 #include "pn_common.h"
 
+// Test hook of the create-time DSP self-test (pn_context.cpp: dsp_selftest): when > 0, every DSP launcher caps its grid
+// at this many blocks, so that a 40-stream batch walks several grid-stride rounds of ONE block (the regime in which a
+// mis-scheduled persistent loop once corrupted later rounds).  0 in normal operation.
+extern int g_pn_dsp_grid_cap;
+
 // ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
 struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
 // in: stream s's 480 samples at in + s*in_stride; i16_scale: 1/32768 (CLI, main.cpp:34) or 1 (training binary,

@@ -638,6 +638,31 @@ def test_front_end_kernel_families_agree_bit_for_bit(model, oracle):
     assert (rs == 0).any()                       # non-silent frames: the comb-filtered spectrum mattered
 
 
+def test_create_time_self_tests_run_and_pass(blob, tmp_path):
+    """pn_ctx_create runs two known-answer self-tests once per (device, kernel family) and process: the MFMA network
+    kernels against the reference-order kernels on a built-in weight set, and the DSP kernels on a built-in waveform
+    against the CPU oracle's stored 70 features + 14 silence flags (40 streams squeezed through ONE block's grid-stride
+    loop).  PERCEPNET_SELFTEST=2 reports them on stderr; every front-end family must pass."""
+    import subprocess, sys, textwrap
+    (tmp_path / "m.pnw").write_bytes(blob)
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r)
+        from percepnet_amd import api
+        m = api.Model(open(%r, "rb").read())
+        for mode in (api.NN_MFMA, api.NN_MFMA_F16):
+            c = api.Context(m, 300, nn_mode=mode); c.close()
+        c = api.Context(m, 5000, nn_mode=api.NN_MFMA); c.close()
+        print("created")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "m.pnw"))
+    for fam in ("split", "mono", "g2"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, PERCEPNET_SELFTEST="2", PERCEPNET_FE=fam))
+        assert r.returncode == 0 and "created" in r.stdout, r.stderr[-2000:]
+        assert r.stderr.count("DSP self-test") == 1 and "bit-equal to the CPU oracle, 40 streams identical" in r.stderr, r.stderr[-2000:]
+        assert r.stderr.count("network self-test") == 3, r.stderr[-2000:]          # small fp32, small... fp16, batch fp32 families
+        assert "FAILED" not in r.stderr and "SKIPPED" not in r.stderr
+
+
 def test_extreme_inputs_strict_bit_exact(model, oracle):
     """Inputs at the edges of the int16 range: full-scale square wave, alternating +-32768/32767, a lone impulse, DC at
     both rails, white noise at full scale.  The CLI's float->int16 conversion truncates and WRAPS (main.cpp:36, no
