@@ -132,7 +132,7 @@ static const char *kKernelNames[KF_COUNT] = {"frontend", "fc", "conv1", "conv2",
                                             "fe_spec_in", "fe_pitch", "fe_spec_out"};
 enum { FE_MONO_G4 = 0, FE_MONO_G2 = 1, FE_SPLIT = 2 };
 
-struct DevLayer { float *bias, *w, *rw, *wp, *rwp; };
+struct DevLayer { float *bias, *w, *rw, *wp, *rwp, *wq; };   // wq: narrow layers of small-batch fp32 contexts (pn_pack_weights_n16)
 
 struct pn_ctx {
   int device, B, nn_mode;
@@ -242,6 +242,13 @@ static int pn_fe_mode_for(int n_streams) {
   if (const char *e = getenv("PERCEPNET_FE_G2")) return atoi(e) ? FE_MONO_G2 : FE_MONO_G4;
   (void)n_streams;
   return FE_SPLIT;      // measured: 0.102 vs 0.124 ms (g2) at 1024 streams, 0.130 vs 0.166 (g4) at 4096, 1.32 vs 2.37 at 65536 (profiles/r03e_*)
+}
+// narrow (34-column) dense layers on 16x16x4 MFMA tiles (pn_dense_n16_kernel) up to this batch size (measured: fc_gb 0.026 vs
+// 0.056 ms at 1024 streams, 0.082 vs 0.101 at 16384, 0.327 vs 0.180 at 65536 where the batch GEMM's operand reuse wins);
+// PERCEPNET_N16_ROWS overrides
+static bool n16_rows_ok(int n_streams) {
+  const char *e = getenv("PERCEPNET_N16_ROWS");
+  return n_streams <= (e ? atoi(e) : 20480);
 }
 static int nn_selftest(pn_ctx *c);
 static int dsp_selftest(pn_ctx *c);
@@ -359,6 +366,12 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
         pn_pack_weights(H.w, K, k_alloc, ncols, ctr, packed.data());
         if (upload(c, &c->L[li].wp, packed.data(), packed.size())) goto fail;
         if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
+        if (n16_rows_ok(n_streams) && H.kind == PN_KIND_DENSE && ncols <= 48 && K % 128 == 0) {     // fc_gb, fc_rb
+          std::vector<float> pq(pn_packed_floats_n16(K, ncols));
+          pn_pack_weights_n16(H.w, K, ncols, pq.data());
+          if (upload(c, &c->L[li].wq, pq.data(), pq.size())) goto fail;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+        }
         if (nr) {
           std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
           pn_pack_weights(H.rw, H.nn, H.nn, ncols, 1, rp.data());
@@ -511,10 +524,12 @@ static void launch_rnn(pn_ctx *c) {
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
     if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
+    else if (c->L[PN_L_FC_GB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
   { Scope sc(c, KF_FC_RB);
     PnSegs A = seg1(rbn, 128, 128);
     if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, NULL, 0, (int)B);
+    else if (c->L[PN_L_FC_RB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B, c->small); }
 }
 

@@ -49,6 +49,11 @@ void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float 
                        const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
                        float *h_new, void *h_newH, int n_rows);
 int pn_dense_nt(int N);
+// narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
+size_t pn_packed_floats_n16(int K, int ncols);
+void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);
+void pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, int n_rows);
 // small: 1 = the small-batch kernel family (pn_nn_small.hip), 0 = the batch-GEMM kernels; ignored when strict.
 // pn_small_rows(): the batch size up to which a context picks the small family (PERCEPNET_SMALL_ROWS, default 4096).
 int pn_small_rows();

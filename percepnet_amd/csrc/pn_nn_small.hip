@@ -205,6 +205,115 @@ __global__ __launch_bounds__(192) void pn_gru_small_kernel(
   }
 }
 
+
+// ---- narrow dense layers (fc_gb: 2560 -> 34, fc_rb: 128 -> 34) in the latency regime -------------------------------------------
+// With 32x32 tiles a 34-column layer wastes 47 % of its MFMAs on padding and, worse for one frame's latency, every
+// output hangs on a K/2-long chain of 64-cycle v_mfma_f32_32x32x2_f32 (fc_gb: 1280 of them = 34 us however few rows).
+// v_mfma_f32_16x16x4_f32 retires four k per 32-cycle issue (40 dependent) and is the SAME k-ascending fmaf chain bit for
+// bit (tools/probes/mfma16_korder_probe.hip: 256/256 outputs), so a wave here owns one 16-row x 16-column tile and one
+// accumulator: fc_gb's chain is 640 instructions.  One wave per block, nothing shared, no barrier:
+//   * weights pre-packed per (16-column tile, 16-k group, lane) as float4 = the lane's b for four consecutive MFMAs
+//     (pn_pack_weights_n16): one coalesced 1 KB load per four MFMAs;
+//   * activations: lane (row r, k-quarter g) loads A[r][16t + 4g .. +3]; the MFMA wants lane (r, g) to feed k = 4e + g,
+//     a 4x4 transpose inside each 16-float run, done through a wave-private LDS tile (one ds_write_b128, four
+//     ds_read_b32 per four MFMAs);
+//   * eight 16-k groups of both operands in flight (the chain is paced by L2 latency, not bandwidth).
+// Chain order = bias, then k ascending: identical to the other kernel families and to sgemv_accum (nnet.cpp:59-72).
+#define N16_DEPTH 8
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64, 1) void pn_dense_n16_kernel(        // (64, 1): one wave per block, up to 512 registers — no spills
+    PnSegs A, const float *__restrict__ Wq, const float *__restrict__ bias, int N, int KG, int lg_gps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_ctiles) {
+  __shared__ __attribute__((aligned(16))) float T[2][16][20];     // transposing tile, rows padded to 20 floats
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const int mt = blockIdx.x / n_ctiles, ct = blockIdx.x - mt * n_ctiles;
+  const int m0 = mt * 16, col = ct * 16 + r;
+  floatx4 acc;
+  {
+    const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = bv;
+  }
+  PN_PANEL_LOCALS(A);
+  const float *wq = Wq + ((size_t)ct * KG) * 256 + lane * 4;
+  const size_t arow = (size_t)(m0 + r) * pld + 4 * g;
+  // group t (16 k): panel t >> lg_gps (panel widths are powers of two: 128, 512), k offset 16 (t mod groups-per-panel)
+  auto a_ptr = [&](int t) { const int sg = t >> lg_gps; return pn_seg_ptr(PN_PANEL_PASS, sg) + arow + 16 * (t - (sg << lg_gps)); };
+  // Two register sets of eight 16-k groups each (named registers: as arrays the compiler left them in scratch memory).
+  // While one set feeds 32 MFMAs (~1300 cycles) the 16 loads of the other are in flight — more than an L2 round trip.
+  // (A rolling eight-deep prefetch with one load pair per group was tried first: across the loop back-edge the compiler's
+  // wait-count pass falls back to vmcnt(0) before every use, which exposes the full load latency per group.)
+  float4 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7;
+  float4 qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7, qb0, qb1, qb2, qb3, qb4, qb5, qb6, qb7;
+#define N16_FILL(RA, RB, t_) do { const int tt_ = (t_) < KG ? (t_) : KG - 1;    /* past the end: re-read the last group, unused */ \
+    RA = *reinterpret_cast<const float4 *>(a_ptr(tt_)); RB = *reinterpret_cast<const float4 *>(wq + (size_t)tt_ * 256); } while (0)
+#define N16_FILL_SET(P, t_) do { N16_FILL(P##a0, P##b0, (t_)); N16_FILL(P##a1, P##b1, (t_) + 1); N16_FILL(P##a2, P##b2, (t_) + 2);   \
+    N16_FILL(P##a3, P##b3, (t_) + 3); N16_FILL(P##a4, P##b4, (t_) + 4); N16_FILL(P##a5, P##b5, (t_) + 5);                            \
+    N16_FILL(P##a6, P##b6, (t_) + 6); N16_FILL(P##a7, P##b7, (t_) + 7); } while (0)
+#define N16_GROUP(d_, RA, RB) do {                                                                             \
+    float (*Tt)[20] = T[(d_) & 1];                                                                             \
+    *reinterpret_cast<float4 *>(&Tt[r][4 * g]) = RA;                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();                    \
+    const float a0_ = Tt[r][g], a1_ = Tt[r][4 + g], a2_ = Tt[r][8 + g], a3_ = Tt[r][12 + g];                   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_, RB.x, acc, 0, 0, 0);                                       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_, RB.y, acc, 0, 0, 0);                                       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_, RB.z, acc, 0, 0, 0);                                       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_, RB.w, acc, 0, 0, 0);                                       \
+  } while (0)
+#define N16_RUN_SET(P) do { N16_GROUP(0, P##a0, P##b0); N16_GROUP(1, P##a1, P##b1); N16_GROUP(2, P##a2, P##b2);                     \
+    N16_GROUP(3, P##a3, P##b3); N16_GROUP(4, P##a4, P##b4); N16_GROUP(5, P##a5, P##b5); N16_GROUP(6, P##a6, P##b6);                  \
+    N16_GROUP(7, P##a7, P##b7); } while (0)
+  N16_FILL_SET(p, 0);
+#pragma unroll 1
+  for (int t0 = 0;; t0 += 2 * N16_DEPTH) {           // KG is a multiple of N16_DEPTH (launcher)
+    N16_FILL_SET(q, t0 + N16_DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+    N16_RUN_SET(p);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t0 + N16_DEPTH >= KG) break;
+    N16_FILL_SET(p, t0 + 2 * N16_DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+    N16_RUN_SET(q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t0 + 2 * N16_DEPTH >= KG) break;
+  }
+#undef N16_RUN_SET
+#undef N16_GROUP
+#undef N16_FILL_SET
+#undef N16_FILL
+  if (col < N) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = m0 + 4 * g + i;                 // D[4 (lane / 16) + i][lane % 16]
+      if (row < n_rows) out[(size_t)row * ldo + col] = pn_act(acc[i], act, tansig);
+    }
+  }
+}
+
+// weights of a narrow layer for pn_dense_n16_kernel: Wq[ct][t][lane][e] = W[k = 16t + 4e + (lane >> 4)][col = 16 ct + (lane & 15)]
+size_t pn_packed_floats_n16(int K, int ncols) { return (size_t)((ncols + 15) / 16) * ((K + 15) / 16) * 256; }
+void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq) {
+  const int CT = (ncols + 15) / 16, KG = (K + 15) / 16;
+  for (int ct = 0; ct < CT; ct++)
+    for (int t = 0; t < KG; t++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 4; e++) {
+          const int k = 16 * t + 4 * e + (lane >> 4), c = 16 * ct + (lane & 15);
+          Wq[(((size_t)ct * KG + t) * 64 + lane) * 4 + e] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
+        }
+}
+void pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
+                         const float *tansig, float *out, int ldo, int n_rows) {
+  const int gps = A.width[0] / 16, KG = gps * A.n;      // equal-width panels, widths multiples of 16 (128, 512)
+  const int n_mt = (n_rows + 15) / 16, n_ct = (N + 15) / 16;
+  if (KG % N16_DEPTH) { pn_set_error("pn_launch_dense_n16: %d k-groups (must be a multiple of %d)", KG, N16_DEPTH); return; }
+  int lg = 0;
+  while ((1 << lg) < gps) lg++;
+  if ((1 << lg) != gps) { pn_set_error("pn_launch_dense_n16: panel width %d is not a power of two", A.width[0]); return; }
+  hipLaunchKernelGGL(pn_dense_n16_kernel, dim3(n_mt * n_ct), dim3(64), 0, st, A, Wq, bias, N, KG, lg, act, tansig, out, ldo,
+                     n_rows, n_ct);
+}
+
 // ---- launchers (called from pn_launch_dense / pn_launch_gru when the batch is small) -------------------------------
 void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
                            const float *tansig, float *out, int ldo, int n_rows, int ct_padded) {
