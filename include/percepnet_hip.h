@@ -70,7 +70,7 @@ int pn_ctx_n_streams(const pn_ctx *ctx);
 int64_t pn_ctx_frames_done(const pn_ctx *ctx);
 size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state + weights */
 /* Which kernel families this context launches (chosen at creation from its batch size and nn_mode), as a
-   NUL-terminated "key=value ..." string, e.g. "nn=mfma_f32 dense=batch gru=batch gru_rb=batch frontend=split".
+   NUL-terminated "key=value ..." string, e.g. "nn=mfma_f32 dense=batch gru=batch gru_rb=batch narrow=n16 frontend=split".
    Returns the length written (excluding the NUL) or -1. */
 int pn_ctx_describe(const pn_ctx *ctx, char *buf, size_t buf_bytes);
 

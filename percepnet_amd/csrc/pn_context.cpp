@@ -399,8 +399,9 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : "mfma_f32");
   const bool fam = c->nn_mode == PN_NN_MFMA;            // the small-batch family exists for the fp32 MFMA mode only
-  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
-                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch", c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
+  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
+                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch",
+                         c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
   return (w < 0 || (size_t)w >= n) ? -1 : w;
 }
 extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
