@@ -298,3 +298,12 @@ void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int
   hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams, PN_FS_WAVES_OUT)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
                      slot_r, hist, yring, eyring, last_period, Ps, feat, silence, aux);
 }
+
+// The three phase kernels in sequence = pn_launch_frontend (same arguments, same results bit for bit).
+void pn_launch_frontend_split(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
+                              long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, float2 *Ps,
+                              float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
+  pn_launch_fe_spec_in(st, T, n_streams, frame, in, in_is_i16, in_stride, i16_scale, hist, yring, eyring);
+  pn_launch_fe_pitch(st, n_streams, frame, hist, feat, last_period, last_gain, aux);
+  pn_launch_fe_spec_out(st, T, n_streams, frame, hist, yring, eyring, last_period, Ps, feat, silence, aux);
+}

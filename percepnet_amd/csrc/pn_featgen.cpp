@@ -122,12 +122,13 @@ static int fg_frame(pn_featgen *c, const int16_t *sp, const int16_t *no, long lo
   const size_t B = c->B;
   // train() analyses the noisy frame first (730) and the speech frame second (731); the two states are
   // independent, so the order of the launches is immaterial
-  pn_launch_frontend(c->stream, c->tables, c->B, c->t, no, 1, in_stride, 1.f, c->noisy.hist, c->noisy.yring,
-                     c->noisy.eyring, c->noisy.Ps, c->noisy.feat, c->noisy.silence, c->noisy.last_period,
-                     c->noisy.last_gain, c->noisy.aux);
-  pn_launch_frontend(c->stream, c->tables, c->B, c->t, sp, 1, in_stride, 1.f, c->clean.hist, c->clean.yring,
-                     c->clean.eyring, c->clean.Ps, c->clean.feat, c->clean.silence, c->clean.last_period,
-                     c->clean.last_gain, c->clean.aux);
+  // the phase-split front end (three launches per analysed signal) unless PERCEPNET_FE=mono asks for the single-launch kernel
+  static const bool mono = getenv("PERCEPNET_FE") && (!strcmp(getenv("PERCEPNET_FE"), "mono") || !strcmp(getenv("PERCEPNET_FE"), "g4"));
+  auto fe = mono ? pn_launch_frontend : pn_launch_frontend_split;
+  fe(c->stream, c->tables, c->B, c->t, no, 1, in_stride, 1.f, c->noisy.hist, c->noisy.yring, c->noisy.eyring, c->noisy.Ps,
+     c->noisy.feat, c->noisy.silence, c->noisy.last_period, c->noisy.last_gain, c->noisy.aux);
+  fe(c->stream, c->tables, c->B, c->t, sp, 1, in_stride, 1.f, c->clean.hist, c->clean.yring, c->clean.eyring, c->clean.Ps,
+     c->clean.feat, c->clean.silence, c->clean.last_period, c->clean.last_gain, c->clean.aux);
   pn_launch_targets(c->stream, c->tables, c->B, c->clean.eyring + (size_t)slot_r * B * 36,
                     c->noisy.eyring + (size_t)slot_r * B * 36, c->noisy.eyring + (size_t)slot_w * B * 36, c->clean.aux,
                     c->noisy.aux, c->noisy.last_period, rec, rec_stride, c->gr);

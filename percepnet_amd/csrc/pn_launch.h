@@ -29,6 +29,9 @@ void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const floa
 void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const float *hist,
                            const float2 *yring, const float *eyring, const int *last_period, float2 *Ps, float *feat,
                            int *silence, float *aux);
+void pn_launch_frontend_split(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
+                              long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, float2 *Ps,
+                              float *feat, int *silence, int *last_period, float *last_gain, float *aux);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,
