@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpercepnet_hip.so")
 
-NN_MFMA, NN_STRICT, NN_MFMA_F16 = 0, 1, 2
+NN_MFMA, NN_STRICT, NN_MFMA_F16, NN_MFMA_X3 = 0, 1, 2, 3
 FRAME = 480
 
 _vp = ctypes.c_void_p

@@ -203,6 +203,9 @@ static int upload(pn_ctx *c, float **dst, const float *src, size_t n) {
   return 0;
 }
 
+// operand shadows: 1 half per element (fp16-operand mode) or a hi and a lo plane (split-precision mode)
+static size_t shadow_halfs_per_element(const pn_ctx *c) { return c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1; }
+static bool x3_layer(int li) { return li == PN_L_CONV1 || li == PN_L_CONV2 || li == PN_L_GRU_RB || (li >= PN_L_GRU1 && li < PN_L_GRU1 + 4); }
 static int zero_state(pn_ctx *c) {
   const size_t B = c->B;
   PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST_STRIDE * 4, c->stream));
@@ -221,11 +224,12 @@ static int zero_state(pn_ctx *c) {
   PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * Bp * 128 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->gr, 0, B * 68 * 4, c->stream));
   if (c->c1ringH) {
-    PN_HIP_CHECK(hipMemsetAsync(c->c1ringH, 0, 5 * Bp * 128 * 2, c->stream));
-    PN_HIP_CHECK(hipMemsetAsync(c->c2ringH, 0, 3 * Bp * 512 * 2, c->stream));
-    PN_HIP_CHECK(hipMemsetAsync(c->c2outH, 0, Bp * 512 * 2, c->stream));
-    for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gruH[i], 0, 2 * Bp * 512 * 2, c->stream));
-    PN_HIP_CHECK(hipMemsetAsync(c->rbH, 0, 2 * Bp * 128 * 2, c->stream));
+    const size_t hb = 2 * shadow_halfs_per_element(c);   // shadow bytes per element
+    PN_HIP_CHECK(hipMemsetAsync(c->c1ringH, 0, 5 * Bp * 128 * hb, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->c2ringH, 0, 3 * Bp * 512 * hb, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->c2outH, 0, Bp * 512 * hb, c->stream));
+    for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gruH[i], 0, 2 * Bp * 512 * hb, c->stream));
+    PN_HIP_CHECK(hipMemsetAsync(c->rbH, 0, 2 * Bp * 128 * hb, c->stream));
   }
   c->t = 0; c->tn = 0;
   return 0;
@@ -281,7 +285,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
                           int force_small, int force_small_gru) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
-  if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
+  if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16 && nn_mode != PN_NN_MFMA_X3) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     pn_set_error("no HIP device available (this library has no CPU fallback)");
@@ -327,12 +331,13 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * Bp * 512, false);
   DEV_ALLOC(c->rb, 2 * Bp * 128, false);
   DEV_ALLOC(c->gr, B * 68, false);
-  if (nn_mode == PN_NN_MFMA_F16) {
-    DEV_ALLOC(c->c1ringH, 5 * Bp * 128, false);
-    DEV_ALLOC(c->c2ringH, 3 * Bp * 512, false);
-    DEV_ALLOC(c->c2outH, Bp * 512, false);
-    for (int i = 0; i < 4; i++) DEV_ALLOC(c->gruH[i], 2 * Bp * 512, false);
-    DEV_ALLOC(c->rbH, 2 * Bp * 128, false);
+  if (nn_mode == PN_NN_MFMA_F16 || nn_mode == PN_NN_MFMA_X3) {
+    const size_t hp = shadow_halfs_per_element(c);      // 1: fp16 shadow; 2: hi + lo planes (split precision)
+    DEV_ALLOC(c->c1ringH, hp * 5 * Bp * 128, false);
+    DEV_ALLOC(c->c2ringH, hp * 3 * Bp * 512, false);
+    DEV_ALLOC(c->c2outH, hp * Bp * 512, false);
+    for (int i = 0; i < 4; i++) DEV_ALLOC(c->gruH[i], hp * 2 * Bp * 512, false);
+    DEV_ALLOC(c->rbH, hp * 2 * Bp * 128, false);
   }
   DEV_ALLOC(c->io_in, B * PN_FRAME, false);
   DEV_ALLOC(c->io_out, B * PN_FRAME, false);
@@ -350,7 +355,19 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
       const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
       const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
       const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
-      if (nn_mode == PN_NN_MFMA_F16) {
+      if (nn_mode == PN_NN_MFMA_X3 && x3_layer(li)) {      // conv1, conv2 and the GRUs; fc / fc_gb / fc_rb stay fp32 below
+        const int ctx3 = H.kind == PN_KIND_GRU ? 1 : pn_dense_x3_nt(H.nn);
+        std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3));
+        if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the split-precision mode cannot represent it", li); goto fail; }
+        if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
+        if (nr) {
+          std::vector<uint16_t> rp(pn_packed_halfs_x3(H.nn, ncols, 1));
+          if (pn_pack_weights_x3(H.rw, H.nn, H.nn, ncols, 1, rp.data())) { pn_set_error("layer %d has a recurrent weight outside the fp16 range", li); goto fail; }
+          if (upload(c, &c->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
+        }
+      } else if (nn_mode == PN_NN_MFMA_F16) {
         std::vector<uint16_t> packed(pn_packed_halfs(k_alloc, ncols, ctr));
         pn_pack_weights_f16(H.w, K, k_alloc, ncols, ctr, packed.data());
         if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
@@ -397,7 +414,7 @@ extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
 extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
 extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
-  const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : "mfma_f32");
+  const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
   const bool fam = c->nn_mode == PN_NN_MFMA;            // the small-batch family exists for the fp32 MFMA mode only
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
                          fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch",
@@ -471,7 +488,7 @@ static uint16_t *shadow(pn_ctx *c, const float *p) {
       {c->c1ring, c->c1ringH, 5 * Bp * 128}, {c->c2ring, c->c2ringH, 3 * Bp * 512}, {c->c2out, c->c2outH, Bp * 512},
       {c->gru[0], c->gruH[0], 2 * Bp * 512}, {c->gru[1], c->gruH[1], 2 * Bp * 512}, {c->gru[2], c->gruH[2], 2 * Bp * 512},
       {c->gru[3], c->gruH[3], 2 * Bp * 512}, {c->rb, c->rbH, 2 * Bp * 128}};
-  for (auto &e : m) if (p >= e.f && p < e.f + e.n) return e.h + (p - e.f);
+  for (auto &e : m) if (p >= e.f && p < e.f + e.n) return e.h + shadow_halfs_per_element(c) * (size_t)(p - e.f);
   return NULL;
 }
 static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
@@ -482,7 +499,7 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
 
 static void launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
-  const bool f16 = c->nn_mode == PN_NN_MFMA_F16;
+  const bool f16 = c->nn_mode == PN_NN_MFMA_F16, x3 = c->nn_mode == PN_NN_MFMA_X3;
   hipStream_t st = c->stream; const float *tab = c->tansig;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
   float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128;
@@ -490,16 +507,19 @@ static void launch_rnn(pn_ctx *c) {
   { Scope sc(c, KF_FC);
     PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
     if (f16) pn_launch_dense_f16(st, A, 0, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, shadow(c, c1new), 128, (int)B);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small); }
+    else pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
+    if (x3) pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp); }   // fc runs in fp32 (70 inputs); its output enters the split-precision layers
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 512, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B);
+    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B, c->small); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 512, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B);
+    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B, c->small); }
   const float *x = c->c2out;
   for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
@@ -507,7 +527,8 @@ static void launch_rnn(pn_ctx *c) {
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
+    else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
     else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
     x = hn;
   }
@@ -518,7 +539,8 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
+    else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
     else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
@@ -868,7 +890,7 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
 static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2, float *const gru[4], float *rb) {
   PN_ON_DEVICE(c);
   if (pipe_drain(c)) return -1;
-  if (c->nn_mode == PN_NN_MFMA_F16) { pn_set_error("RNN state load/store is not available in the fp16-operand mode (shadow buffers)"); return -1; }
+  if (c->nn_mode == PN_NN_MFMA_F16 || c->nn_mode == PN_NN_MFMA_X3) { pn_set_error("RNN state load/store is not available in the fp16-operand and split-precision modes (shadow buffers)"); return -1; }
   const size_t B = c->B, Bp = c->Bp; const int64_t t = c->tn;
   const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
   auto cp2d = [&](float *host, size_t hpitch, float *dev, size_t dpitch, size_t width) -> hipError_t {

@@ -52,6 +52,17 @@ void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float 
                        const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
                        float *h_new, void *h_newH, int n_rows);
 int pn_dense_nt(int N);
+// split-precision variant (pn_nn_x3.hip): operands as fp16 hi/lo planes in fragment order; panels of A / h_oldS / outS /
+// h_newS are the uint4* shadows (carried as float* in PnSegs), width = logical columns (multiple of 32)
+size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round);
+int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);   // -1: weight outside fp16 range
+int pn_dense_x3_nt(int N);
+void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows);
+void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
+                      const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
+                      int n_rows);
+void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded);
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);

@@ -178,6 +178,16 @@ __device__ __forceinline__ void pn_lds_read_q(PnHalfOps<NB> &o, const float (*As
 #pragma unroll
   for (int t = 0; t < NB; t++) o.b[t][QQ] = *reinterpret_cast<const float4 *>(&Bs[32 * t + r][q * 8 + kh * 4]);
 }
+// the same with the weight tiles in FRAGMENT order (the global packing, copied verbatim by LDS-DMA): tile t at Bf + 1024 t,
+// float4 number q*64 + lane = the four k-steps (q, kh = lane >> 5) of column lane & 31 — consecutive lanes, consecutive 16 bytes
+template <int NB, int HF, int QQ>
+__device__ __forceinline__ void pn_lds_read_qf(PnHalfOps<NB> &o, const float (*As)[LDT], const float *Bf, int wave, int lane) {
+  const int r = lane & 31, kh = lane >> 5;
+  constexpr int q = 2 * HF + QQ;
+  o.a[QQ] = *reinterpret_cast<const float4 *>(&As[32 * wave + r][q * 8 + kh * 4]);
+#pragma unroll
+  for (int t = 0; t < NB; t++) o.b[t][QQ] = *reinterpret_cast<const float4 *>(Bf + 1024 * t + (q * 64 + lane) * 4);
+}
 // one k-step (2 k values) of a GRU half tile: 3 MFMAs
 #define PN_G3(o, QQ, c, I0, I1, I2) do {                                                                   \
     acc[I0] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[0][QQ].c, acc[I0], 0, 0, 0);         \
@@ -271,11 +281,62 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                         \
     const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
 #define GP_LA(it) pn_load_so(ap_, p1_ ? aox[it] : aoh[it])
+#ifdef PN_NN_BDMA
+  // Weight tiles by LDS-DMA (global_load_lds_dwordx4): tile g+1 is copied during interval g straight into the other B
+  // buffer in its packed fragment order — no staging registers, no ds_write for B; each wave moves one 1 KB quarter of
+  // each of the three gate tiles.  The fragment-order images alias S.B (2 x 3072 of its 9216 floats).
+  float *const Bf0 = &S.B[0][0][0], *const Bf1 = Bf0 + 3 * 1024;
+#define GP_BF(BUF) ((BUF) ? Bf1 : Bf0)
+#define GP_SELB(gg)                                                                                       \
+    int gb_ = (gg); gb_ = gb_ < TT ? gb_ : TT - 1;                                                         \
+    const bool pb_ = gb_ < T1;                                                                             \
+    const size_t bob_ = (size_t)(pb_ ? gb_ : gb_ - T1) * 1024;                                             \
+    const float *dz_ = (pb_ ? Wz : Uz) + bob_, *dr_ = (pb_ ? Wr : Ur) + bob_, *dh_ = (pb_ ? Wh : Uh) + bob_
+#define GP_DMA(src, BUF, t) __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(src) + bo4, GP_BF(BUF) + 1024 * (t) + 256 * wave, 16, 0, 0)
+#endif
 #define GP_FETCH_ALL(R, gg) do { GP_SEL(gg);                                                               \
     (R).a[0] = GP_LA(0); (R).a[1] = GP_LA(1); (R).a[2] = GP_LA(2); (R).a[3] = GP_LA(3);                    \
     (R).b[0] = pn_load_so(bz_, bo4); (R).b[1] = pn_load_so(br_, bo4); (R).b[2] = pn_load_so(bh_, bo4); } while (0)
   // One interval.  RF: register set that receives tile g+2; RS: register set holding tile g+1 (stashed into
   // buffer BUF^1).  PI2 / CI2: third accumulator of the previous / current tile (2 = hx for x tiles, 3 = tmp for h).
+#ifdef PN_NN_BDMA
+#define GP_INTERVAL(gg, BUF, RF, RS, PI2, CI2, HAVE_PREV) do {                                             \
+    GP_SEL((gg) + 2); GP_SELB((gg) + 1);                                                                                      \
+    PN_SB();                                                                                               \
+    pn_lds_read_qf<3, 0, 0>(op0, S.A[BUF], GP_BF(BUF), wave, lane); PN_SB();                        \
+    if (HAVE_PREV) PN_G3(op1, 0, x, 0, 1, PI2);                                                            \
+    pn_lds_read_qf<3, 0, 1>(op0, S.A[BUF], GP_BF(BUF), wave, lane); PN_SB();                        \
+    if (HAVE_PREV) PN_G3(op1, 0, y, 0, 1, PI2);                                                            \
+    (RF).a[0] = GP_LA(0); PN_SB();                                      \
+    if (HAVE_PREV) PN_G3(op1, 0, z, 0, 1, PI2);                                                            \
+    (RF).a[1] = GP_LA(1); PN_SB();                                      \
+    if (HAVE_PREV) PN_G3(op1, 0, w, 0, 1, PI2);                                                            \
+    (RF).a[2] = GP_LA(2); PN_SB();                                      \
+    if (HAVE_PREV) PN_G3(op1, 1, x, 0, 1, PI2);                                                            \
+    (RF).a[3] = GP_LA(3); PN_SB();                                      \
+    if (HAVE_PREV) PN_G3(op1, 1, y, 0, 1, PI2);                                                            \
+    GP_DMA(dz_, (BUF) ^ 1, 0); GP_DMA(dr_, (BUF) ^ 1, 1); PN_SB();                                     \
+    if (HAVE_PREV) PN_G3(op1, 1, z, 0, 1, PI2);                                                            \
+    GP_DMA(dh_, (BUF) ^ 1, 2); PN_SB();                                                                \
+    if (HAVE_PREV) PN_G3(op1, 1, w, 0, 1, PI2);                                                            \
+    PN_G3(op0, 0, x, 0, 1, CI2);                                                                           \
+    pn_lds_read_qf<3, 1, 0>(op1, S.A[BUF], GP_BF(BUF), wave, lane); PN_SB();                        \
+    PN_G3(op0, 0, y, 0, 1, CI2);                                                                           \
+    pn_lds_read_qf<3, 1, 1>(op1, S.A[BUF], GP_BF(BUF), wave, lane); PN_SB();                        \
+    PN_G3(op0, 0, z, 0, 1, CI2);                                                                           \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[0], 0); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[1], 1); PN_SB();\
+    PN_G3(op0, 0, w, 0, 1, CI2);                                                                           \
+    pn_store_A1(S.A[(BUF) ^ 1], (RS).a[2], 2); pn_store_A1(S.A[(BUF) ^ 1], (RS).a[3], 3); PN_SB();\
+    PN_G3(op0, 1, x, 0, 1, CI2);                                                                           \
+    PN_SB();                                                                                               \
+    PN_G3(op0, 1, y, 0, 1, CI2);                                                                           \
+    PN_SB();                                                                                               \
+    PN_G3(op0, 1, z, 0, 1, CI2);                                                                           \
+    PN_G3(op0, 1, w, 0, 1, CI2);                                                                           \
+    __syncthreads();                                                                                             \
+  } while (0)
+
+#else
 #define GP_INTERVAL(gg, BUF, RF, RS, PI2, CI2, HAVE_PREV) do {                                             \
     GP_SEL((gg) + 2);                                                                                      \
     PN_SB();                                                                                               \
@@ -312,8 +373,16 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     __syncthreads();                                                                                             \
   } while (0)
 
+#endif
+#ifdef PN_NN_BDMA
+  { GP_SEL(0); R0.a[0] = GP_LA(0); R0.a[1] = GP_LA(1); R0.a[2] = GP_LA(2); R0.a[3] = GP_LA(3);
+    GP_DMA(bz_, 0, 0); GP_DMA(br_, 0, 1); GP_DMA(bh_, 0, 2); }
+  { GP_SEL(1); R1.a[0] = GP_LA(0); R1.a[1] = GP_LA(1); R1.a[2] = GP_LA(2); R1.a[3] = GP_LA(3); }
+  pn_store_A(S.A[0], R0.a);
+#else
   GP_FETCH_ALL(R0, 0); GP_FETCH_ALL(R1, 1);
   pn_tile_stash<3>(S.A[0], S.B[0], R0);
+#endif
   __syncthreads();
   // tile g lives in LDS buffer g&1 and, before that, in register set R(g&1)
   GP_INTERVAL(0, 0, R0, R1, 2, 2, false);
@@ -336,6 +405,11 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
 #undef GP_FETCH_ALL
 #undef GP_LA
 #undef GP_SEL
+#ifdef PN_NN_BDMA
+#undef GP_DMA
+#undef GP_SELB
+#undef GP_BF
+#endif
 #ifdef PN_NN_CLOCKS
   if (tid == 0) {
     atomicAdd(&pn_nn_clk[0], (unsigned long long)(__builtin_readcyclecounter() - c0_));

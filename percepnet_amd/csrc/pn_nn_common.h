@@ -80,13 +80,13 @@ __device__ __forceinline__ float pn_act(float v, int act, const float *tab) {
 // GRU gates, candidate and blend for the 16 outputs of a lane (nnet.cpp:144,156,161-179; activations vec.h:53-75).
 // Staged so that the table reads of all outputs are in flight together: evaluated one output at a time each of the
 // 48 dependent LDS reads costs its full latency.  row0 = first row of the lane (rows row0 + (i&3) + 8(i>>2)).
-__device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float *ho, float bh, int act,
-                                                const float *tab, float *__restrict__ h_new,
-                                                _Float16 *__restrict__ h_newH, int N, int col, int row0, int n_rows) {
+// v[i] = new state of the lane's i-th output from the four accumulators z, r, hx (W_h x), tmp (U_h h + b)
+__device__ __forceinline__ void pn_gru_gate16(const floatx16 &az_, const floatx16 &ar_, const floatx16 &ahx, const floatx16 &atmp,
+                                              const float (&ho)[16], float bh, int act, const float *tab, float (&v)[16]) {
   PnTsArg az[16], ar[16];
   float tz[16], tr[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) { az[i] = pn_tansig_arg(.5f * acc[0][i]); ar[i] = pn_tansig_arg(.5f * acc[1][i]); }
+  for (int i = 0; i < 16; i++) { az[i] = pn_tansig_arg(.5f * az_[i]); ar[i] = pn_tansig_arg(.5f * ar_[i]); }
 #pragma unroll
   for (int i = 0; i < 16; i++) { tz[i] = tab[az[i].i]; tr[i] = tab[ar[i].i]; }
   float z[16], hp[16];
@@ -95,8 +95,8 @@ __device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float
     z[i] = .5f + .5f * pn_tansig_fin(az[i], tz[i]);                 // sigmoid_approx
     const float r = .5f + .5f * pn_tansig_fin(ar[i], tr[i]);
     float h = bh;
-    h += acc[3][i] * r;
-    hp[i] = h + acc[2][i];
+    h += atmp[i] * r;
+    hp[i] = h + ahx[i];
   }
   if (act == ACT_TANH || act == ACT_SIGMOID) {
     PnTsArg ah[16];
@@ -115,13 +115,20 @@ __device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float
     for (int i = 0; i < 16; i++) hp[i] = hp[i] < 0 ? 0 : hp[i];
   }
 #pragma unroll
+  for (int i = 0; i < 16; i++) v[i] = z[i] * ho[i] + (1 - z[i]) * hp[i];
+}
+__device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float (&ho)[16], float bh, int act,
+                                                const float *tab, float *__restrict__ h_new,
+                                                _Float16 *__restrict__ h_newH, int N, int col, int row0, int n_rows) {
+  float v[16];
+  pn_gru_gate16(acc[0], acc[1], acc[2], acc[3], ho, bh, act, tab, v);
+#pragma unroll
   for (int i = 0; i < 16; i++) {
     const int row = row0 + (i & 3) + 8 * (i >> 2);
     if (row < n_rows) {
-      const float v = z[i] * ho[i] + (1 - z[i]) * hp[i];
-      h_new[(size_t)row * N + col] = v;
+      h_new[(size_t)row * N + col] = v[i];
       // fp16 shadow for the fp16-operand variant, tile-major [M tile][column tile][128][32] (pn_nn_f16.hip)
-      if (h_newH) h_newH[(((size_t)(row / BM) * (N >> 5) + (col >> 5)) * BM + (row % BM)) * 32 + (col & 31)] = (_Float16)v;
+      if (h_newH) h_newH[(((size_t)(row / BM) * (N >> 5) + (col >> 5)) * BM + (row % BM)) * 32 + (col & 31)] = (_Float16)v[i];
     }
   }
 }

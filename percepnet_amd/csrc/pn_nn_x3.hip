@@ -1,0 +1,371 @@
+// Split-precision network kernels for gfx950 (nn_mode PN_NN_MFMA_X3): fp32 GEMMs of the gain network evaluated on
+// the fp16 matrix cores with error compensation, fp32 accumulation and fp32 state.
+//
+// Every GEMM operand x (activation or weight, fp32) is carried as two fp16 numbers, hi = fp16(x) and
+// lo = fp16(x - hi) (x - hi is exact in fp32; v_mfma_f32_32x32x16_f16 honours fp16 subnormals on gfx950 —
+// tools/probes/mfma_f16_denorm_probe.hip — so lo keeps an absolute precision of 2^-25 for |x| <= 1 and a relative
+// precision of 2^-22 above), and every product a*b is formed as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  by three MFMAs into
+// the same fp32 accumulator; the dropped a_lo*b_lo term is below 2^-22 |a b|.  The operand error of a length-1024 dot
+// product is then ~5x SMALLER than the rounding error the reference's own sequential fp32 accumulation makes
+// (tools/x3_error_model.py), so the deviation of this mode from the CPU path is, like PN_NN_MFMA's, the summation
+// order — measured against the same bounds (+-1 LSB PCM, 2e-5 on g/r; tests/test_gpu_x3.py).  The fp16 matrix
+// cores run 16x the fp32 MFMA rate: three products still leave 5.3x, which moves these GEMMs from MFMA-bound to
+// LDS/L2-bound.  Bias preload, table tanh/sigmoid, gating, the state blend and every stored state value stay fp32.
+//
+// Tiling (different from pn_nn.hip because the limiter is different):
+//   block = 4 waves x 64 rows = 256 streams, NT column tiles of 32 (the three gate tiles of one n-tile for a GRU);
+//   A (activations) is NOT staged through LDS: a wave's rows are private to it, so its MFMA fragments are loaded
+//   straight from global memory into registers from a FRAGMENT-ORDER shadow of the producing layer's output,
+//     shadow[M tile of 128][column tile of 32][plane hi|lo][k-group of 8][row 0..127][8 halfs]        (8 KB per plane)
+//   — lane (row r, k-half kh) of k-step s reads the 16 bytes (k-group 2s+kh, row r): 512 contiguous bytes per 32 lanes;
+//   the producer block writes its 256 x 32 output tile as whole 8 KB runs.  Four k-steps of A stay in flight per wave.
+//   B (weights, packed per (column tile, 32 k) as [k-step][plane][lane][8 halfs] = 4 KB) is copied linearly into a
+//   double-buffered LDS image through registers and read back with conflict-free ds_read_b128 (lane-linear).
+//   Per wave and k-step of 16: 4 global loads, 2*NT ds_read_b128, 6*NT MFMAs of 32 cycles -> LDS reads take ~1/3 of
+//   the MFMA time on a CU (with 32-row wave tiles they would take 2/3, with A through LDS more than all of it).
+#include "pn_nn_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+
+#define XM 256                         // rows per block
+#define X3_PLANE 512                   // uint4 per (M tile of 128, column tile, plane): 4 k-groups x 128 rows
+
+struct X3Shared {
+  uint4 B[2][4][4][64];                // [buffer][column tile][2*kstep + plane][lane]: 2 x 16 KB
+  float tansig[208];
+};
+#define X3_TLD 36                      // epilogue stage: 32 rows x 32 columns per wave, rows padded to 36 floats
+static_assert(4 * 32 * X3_TLD * sizeof(float) <= sizeof(uint4) * 2 * 4 * 4 * 64, "stage aliases the weight buffers");
+
+struct X3A { fvec4 h[2], l[2]; };      // one k-step of A fragments: [row group of 32] hi / lo
+
+__device__ __forceinline__ half8 x3_h8(const fvec4 &v) { return __builtin_bit_cast(half8, v); }
+__device__ __forceinline__ half8 x3_h8(const uint4 &v) { return __builtin_bit_cast(half8, v); }
+
+// hi/lo planes of eight consecutive fp32 values (operands beyond the fp16 range saturate instead of turning into NaNs)
+__device__ __forceinline__ void x3_split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
+  half8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const float c = __builtin_fminf(__builtin_fmaxf(v[j], -65504.f), 65504.f);
+    const _Float16 hh = (_Float16)c;
+    h[j] = hh;
+    l[j] = (_Float16)(c - (float)hh);
+  }
+  hi = __builtin_bit_cast(uint4, h); lo = __builtin_bit_cast(uint4, l);
+}
+
+// A fragments of k-step s (0/1) of the 32-k tile at pt (= plane-0 pointer of the lane; plane 1 is X3_PLANE further)
+__device__ __forceinline__ void x3_load_A(X3A &q, const uint4 *__restrict__ pt, int s) {
+  q.h[0] = *reinterpret_cast<const fvec4 *>(pt + s * 256);
+  q.h[1] = *reinterpret_cast<const fvec4 *>(pt + s * 256 + 32);
+  q.l[0] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256);
+  q.l[1] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256 + 32);
+}
+
+// one k-step: acc[rg][IDX[t]] += A * B[t] for both row groups, three products each (small terms first)
+template <int NT, int I0, int I1, int I2, int I3>
+__device__ __forceinline__ void x3_kstep(const X3A &q, const uint4 (*Bs)[4][64], int s, int lane, floatx16 (&acc)[2][4]) {
+  constexpr int IDX[4] = {I0, I1, I2, I3};
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const half8 bh = x3_h8(*reinterpret_cast<const fvec4 *>(&Bs[t][2 * s][lane])), bl = x3_h8(*reinterpret_cast<const fvec4 *>(&Bs[t][2 * s + 1][lane]));
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+      floatx16 a = acc[rg][IDX[t]];
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.l[rg]), bh, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bl, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bh, a, 0, 0, 0);
+      acc[rg][IDX[t]] = a;
+    }
+  }
+}
+
+// Stores one 32 x 32 output tile of a wave (rows row0.., v[i] = value of row (i&3) + 8(i>>2) + 4(lane>>5), column
+// lane&31) through the wave's private LDS stage: fp32 rows as 16-byte stores (out may be null) and the hi/lo shadow
+// planes as one 16-byte store per (row, k-group) (S may be null; Srow = row within the M tile of 128).
+__device__ __forceinline__ void x3_store_tile(float *T, const float (&v)[16], float *__restrict__ out, int ldo, int col0,
+                                              int n_cols, int grow0, int n_rows, uint4 *__restrict__ S, int srow0, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) T[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * X3_TLD + (lane & 31)] = v[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int idx = lane + 64 * p, row = idx >> 2, kg = idx & 3;
+    float f[8];
+    *reinterpret_cast<float4 *>(&f[0]) = *reinterpret_cast<const float4 *>(&T[row * X3_TLD + 8 * kg]);
+    *reinterpret_cast<float4 *>(&f[4]) = *reinterpret_cast<const float4 *>(&T[row * X3_TLD + 8 * kg + 4]);
+    if (out && grow0 + row < n_rows) {
+      float *o = out + (size_t)(grow0 + row) * ldo + col0 + 8 * kg;
+      if (col0 + 32 <= n_cols && (ldo & 3) == 0) {
+        *reinterpret_cast<float4 *>(o) = *reinterpret_cast<const float4 *>(&f[0]);
+        *reinterpret_cast<float4 *>(o + 4) = *reinterpret_cast<const float4 *>(&f[4]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (col0 + 8 * kg + j < n_cols) o[j] = f[j];
+      }
+    }
+    if (S) {
+      uint4 hi, lo;
+      x3_split8(f, hi, lo);
+      S[kg * 128 + srow0 + row] = hi;
+      S[X3_PLANE + kg * 128 + srow0 + row] = lo;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                      // the stage is reused by the next tile of this wave
+}
+
+#define X3_BLOAD(dst, src) (dst) = reinterpret_cast<const fvec4 *>(src)[tid]
+#define X3_BSTASH(buf, t, v) reinterpret_cast<fvec4 *>(&S.B[buf][t][0][0])[tid] = (v)
+
+// ---- dense / conv layer: out = act(bias + A W), NT column tiles per block ----------------------------------------
+// A: shadow panels (PnSegs pointers carry uint4* shadows; width = logical columns of each panel, all equal)
+template <int NT>
+__global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_x3_kernel(
+    PnSegs A, const uint4 *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, uint4 *__restrict__ outS, int nts_out,
+    int n_rows, int n_mtiles, int n_cblocks) {
+  __shared__ X3Shared S;
+  int mt, cb;
+  if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
+  floatx16 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int col = (cb * NT + t) * 32 + (lane & 31);
+    const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[0][t][i] = bv; acc[1][t][i] = bv; }
+  }
+  const int mt128 = 2 * mt + (wave >> 1);
+  const int lane_off = (lane >> 5) * 128 + 64 * (wave & 1) + (lane & 31);
+  const uint4 *wbase = Wp + (size_t)(cb * NT) * KT * 256;
+  PN_PANEL_LOCALS(A);
+  (void)pld;
+  // A tiles are asked for strictly in order (0, 1, 2, ...): a cursor (panel, tile within panel) instead of a division
+  // per tile; past the last tile it keeps returning the last one (loaded, never used)
+  int c_sg = 0, c_kt = 0, c_g = 0;
+  const uint4 *c_last = nullptr;
+#define XD_APTR(gg, pt) \
+    const uint4 *pt; { if (c_g < KT) { \
+        c_last = reinterpret_cast<const uint4 *>(pn_seg_ptr(PN_PANEL_PASS, c_sg)) + ((size_t)mt128 * tps + c_kt) * (2 * X3_PLANE) + lane_off; \
+        c_g++; c_kt++; if (c_kt == tps) { c_kt = 0; c_sg++; } } \
+      pt = c_last; }
+#define XD_BLOAD(gg) do { int g_ = (gg); g_ = g_ < KT ? g_ : KT - 1; \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) X3_BLOAD(rb[t], wbase + ((size_t)t * KT + g_) * 256); } while (0)
+#define XD_BSTASH(buf) do { _Pragma("unroll") for (int t = 0; t < NT; t++) X3_BSTASH(buf, t, rb[t]); } while (0)
+  X3A q0, q1, q2, q3;
+  fvec4 rb[NT];
+  { XD_APTR(0, p0); x3_load_A(q0, p0, 0); x3_load_A(q1, p0, 1); }
+  { XD_APTR(1, p1); x3_load_A(q2, p1, 0); x3_load_A(q3, p1, 1); }
+  XD_BLOAD(0); XD_BSTASH(0); XD_BLOAD(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < KT; g += 2) {
+    { XD_APTR(g + 2, pa);
+      x3_kstep<NT, 0, 1, 2, 3>(q0, S.B[0], 0, lane, acc); x3_load_A(q0, pa, 0);
+      x3_kstep<NT, 0, 1, 2, 3>(q1, S.B[0], 1, lane, acc); x3_load_A(q1, pa, 1); }
+    XD_BSTASH(1); XD_BLOAD(g + 2);
+    __syncthreads();
+    { XD_APTR(g + 3, pb);
+      x3_kstep<NT, 0, 1, 2, 3>(q2, S.B[1], 0, lane, acc); x3_load_A(q2, pb, 0);
+      x3_kstep<NT, 0, 1, 2, 3>(q3, S.B[1], 1, lane, acc); x3_load_A(q3, pb, 1); }
+    XD_BSTASH(0); XD_BLOAD(g + 3);
+    __syncthreads();
+  }
+#undef XD_APTR
+#undef XD_BLOAD
+#undef XD_BSTASH
+  float *T = reinterpret_cast<float *>(&S.B[0][0][0][0]) + wave * 32 * X3_TLD;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int ct = cb * NT + t, col0 = ct * 32;
+    if (col0 >= N) break;
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = pn_act(acc[rg][t][i], act, S.tansig);
+      uint4 *Sx = outS ? outS + ((size_t)mt128 * nts_out + ct) * (2 * X3_PLANE) : nullptr;
+      x3_store_tile(T, v, out, ldo, col0, N, mt * XM + 64 * wave + 32 * rg, n_rows, Sx, 64 * (wave & 1) + 32 * rg, lane);
+    }
+  }
+}
+
+// ---- GRU step (reset-after, nnet.cpp:122-180): acc z, r, hx (W_h x), tmp (U_h h) ---------------------------------
+__global__ __launch_bounds__(NN_THREADS, 2) void pn_gru_x3_kernel(
+    PnSegs X, const float *__restrict__ h_old, const uint4 *__restrict__ h_oldS, const uint4 *__restrict__ Wp,
+    const uint4 *__restrict__ Up, const float *__restrict__ b, int N, int KTx, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ h_new, uint4 *__restrict__ h_newS, int n_rows, int n_mtiles) {
+  __shared__ X3Shared S;
+  const int NTn = N >> 5;
+  int mt, nt;
+  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int KTh = NTn, T1 = KTx, TT = KTx + KTh;
+  const int col = nt * 32 + (lane & 31);
+  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
+  floatx16 acc[2][4];
+  {
+    float bz = b[col]; bz += b[3 * N + col];
+    float br = b[N + col]; br += b[4 * N + col];
+    const float bt = b[5 * N + col];
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) { acc[rg][0][i] = bz; acc[rg][1][i] = br; acc[rg][2][i] = 0.f; acc[rg][3][i] = bt; }
+  }
+  const int mt128 = 2 * mt + (wave >> 1);
+  const int lane_off = (lane >> 5) * 128 + 64 * (wave & 1) + (lane & 31);
+  const uint4 *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 256, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 256,
+              *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 256;
+  const uint4 *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 256, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 256,
+              *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 256;
+  PN_PANEL_LOCALS(X);
+  (void)pld;
+#define XG_SEL(gg) int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1; const bool p1_ = g_ < T1; \
+    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1
+  // A tiles are asked for strictly in order: a cursor over (x panels, then the recurrent operand) instead of a division
+  // per tile; past the last tile it keeps returning the last one (loaded, never used)
+  int c_sg = 0, c_kt = 0, c_g = 0;
+  const uint4 *c_last = nullptr;
+#define XG_APTR(gg, pt) \
+    const uint4 *pt; { if (c_g < T1) { \
+        c_last = reinterpret_cast<const uint4 *>(pn_seg_ptr(PN_PANEL_PASS, c_sg)) + ((size_t)mt128 * tps + c_kt) * (2 * X3_PLANE) + lane_off; \
+        c_kt++; if (c_kt == tps) { c_kt = 0; c_sg++; } \
+      } else if (c_g < TT) { c_last = h_oldS + ((size_t)mt128 * NTn + (c_g - T1)) * (2 * X3_PLANE) + lane_off; } \
+      c_g++; pt = c_last; }
+#define XG_BLOAD(gg) do { XG_SEL(gg); \
+    X3_BLOAD(rb[0], p1_ ? Wz + (size_t)kx_ * 256 : Uz + (size_t)kh_ * 256); \
+    X3_BLOAD(rb[1], p1_ ? Wr + (size_t)kx_ * 256 : Ur + (size_t)kh_ * 256); \
+    X3_BLOAD(rb[2], p1_ ? Wh + (size_t)kx_ * 256 : Uh + (size_t)kh_ * 256); } while (0)
+#define XG_BSTASH(buf) do { X3_BSTASH(buf, 0, rb[0]); X3_BSTASH(buf, 1, rb[1]); X3_BSTASH(buf, 2, rb[2]); } while (0)
+#define XG_PAIR(g, I2)                                                                                   \
+    { XG_APTR((g) + 2, pa);                                                                              \
+      x3_kstep<3, 0, 1, I2, 0>(q0, S.B[0], 0, lane, acc); x3_load_A(q0, pa, 0);                          \
+      x3_kstep<3, 0, 1, I2, 0>(q1, S.B[0], 1, lane, acc); x3_load_A(q1, pa, 1); }                        \
+    XG_BSTASH(1); XG_BLOAD((g) + 2);                                                                     \
+    __syncthreads();                                                                                     \
+    { XG_APTR((g) + 3, pb);                                                                              \
+      x3_kstep<3, 0, 1, I2, 0>(q2, S.B[1], 0, lane, acc); x3_load_A(q2, pb, 0);                          \
+      x3_kstep<3, 0, 1, I2, 0>(q3, S.B[1], 1, lane, acc); x3_load_A(q3, pb, 1); }                        \
+    XG_BSTASH(0); XG_BLOAD((g) + 3);                                                                     \
+    __syncthreads()
+  X3A q0, q1, q2, q3;
+  fvec4 rb[3];
+  { XG_APTR(0, p0); x3_load_A(q0, p0, 0); x3_load_A(q1, p0, 1); }
+  { XG_APTR(1, p1); x3_load_A(q2, p1, 0); x3_load_A(q3, p1, 1); }
+  XG_BLOAD(0); XG_BSTASH(0); XG_BLOAD(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < T1; g += 2) { XG_PAIR(g, 2); }
+#pragma unroll 1
+  for (int g = T1; g < TT; g += 2) { XG_PAIR(g, 3); }
+#undef XG_PAIR
+#undef XG_BSTASH
+#undef XG_BLOAD
+#undef XG_APTR
+#undef XG_SEL
+  {
+    const float bh = b[2 * N + col];
+    float *T = reinterpret_cast<float *>(&S.B[0][0][0][0]) + wave * 32 * X3_TLD;
+    uint4 *Sx = h_newS ? h_newS + ((size_t)mt128 * NTn + nt) * (2 * X3_PLANE) : nullptr;
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+      const int grow0 = mt * XM + 64 * wave + 32 * rg;
+      float ho[16], v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) ho[i] = h_old[(size_t)(grow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
+      pn_gru_gate16(acc[rg][0], acc[rg][1], acc[rg][2], acc[rg][3], ho, bh, act, S.tansig, v);
+      x3_store_tile(T, v, h_new, N, nt * 32, N, grow0, n_rows, Sx, 64 * (wave & 1) + 32 * rg, lane);
+    }
+  }
+}
+
+// ---- fp32 rows -> fragment-order hi/lo shadow (the first layer's output; RNN state loaded from the host) ---------
+// one thread per (row, k-group of 8): reads 32 bytes, writes 2 x 16
+__global__ __launch_bounds__(256) void pn_split_x3_kernel(const float *__restrict__ src, int ld, int width, uint4 *__restrict__ S,
+                                                          int n_rows_padded) {
+  const int kgs = width >> 3;                                    // k-groups per row
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = idx / kgs;
+  const int kgi = (int)(idx - row * kgs);
+  if (row >= (size_t)n_rows_padded) return;
+  float f[8];
+  *reinterpret_cast<float4 *>(&f[0]) = *reinterpret_cast<const float4 *>(src + row * ld + 8 * kgi);
+  *reinterpret_cast<float4 *>(&f[4]) = *reinterpret_cast<const float4 *>(src + row * ld + 8 * kgi + 4);
+  uint4 hi, lo;
+  x3_split8(f, hi, lo);
+  uint4 *chunk = S + ((row >> 7) * (width >> 5) + (kgi >> 2)) * (2 * X3_PLANE);
+  chunk[(kgi & 3) * 128 + (row & 127)] = hi;
+  chunk[X3_PLANE + (kgi & 3) * 128 + (row & 127)] = lo;
+}
+
+// ---- host: weight packing W[K][ncols] -> [CT][ceil(K/32)][k-step 2][plane 2][lane 64][8 halfs] -------------------
+static inline int x3_ct_padded(int ncols, int ct_round) {
+  const int CT = (ncols + 31) / 32;
+  return ((CT + ct_round - 1) / ct_round) * ct_round;
+}
+size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round) {
+  return (size_t)x3_ct_padded(ncols, ct_round) * ((k_alloc + 31) / 32) * 2048;
+}
+// returns 0, or -1 if a weight is outside the fp16 range (the mode cannot represent it)
+int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, void *out) {
+  _Float16 *Wp = (_Float16 *)out;
+  const int CT = x3_ct_padded(ncols, ct_round), KT = (k_alloc + 31) / 32;
+  for (int ct = 0; ct < CT; ct++)
+    for (int kt = 0; kt < KT; kt++) {
+      _Float16 *tile = Wp + ((size_t)ct * KT + kt) * 2048;
+      for (int s = 0; s < 2; s++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int j = 0; j < 8; j++) {
+            const int k = kt * 32 + 16 * s + 8 * (lane >> 5) + j, c = ct * 32 + (lane & 31);
+            const float w = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
+            if (!(w > -65504.f && w < 65504.f)) return -1;
+            const _Float16 hi = (_Float16)w;
+            tile[((2 * s + 0) * 64 + lane) * 8 + j] = hi;
+            tile[((2 * s + 1) * 64 + lane) * 8 + j] = (_Float16)(w - (float)hi);
+          }
+    }
+  return 0;
+}
+
+int pn_dense_x3_nt(int N) { return N >= 128 ? 4 : 2; }
+
+// A: panels carry the uint4* shadows of equally wide buffers (width = logical columns, a multiple of 32);
+// out (fp32, optional) / outS (shadow of a buffer nts_out column tiles wide, optional)
+void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows) {
+  const int tps = A.width[0] / 32, KT = tps * A.n;
+  const int NT = pn_dense_x3_nt(N);
+  const int n_mtiles = (n_rows + XM - 1) / XM;
+  const int n_cblocks = x3_ct_padded(N, NT) / NT;
+  const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
+#define XD_LAUNCH(NT_)                                                                                          \
+  hipLaunchKernelGGL((pn_dense_x3_kernel<NT_>), dim3(grid), dim3(NN_THREADS), 0, st, A, (const uint4 *)Wp, bias, N, \
+                     KT, tps, act, tansig, out, ldo, (uint4 *)outS, nts_out, n_rows, n_mtiles, n_cblocks)
+  if (NT == 4) XD_LAUNCH(4); else XD_LAUNCH(2);
+#undef XD_LAUNCH
+}
+
+void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
+                      const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
+                      int n_rows) {
+  const int tps = X.width[0] / 32, KTx = tps * X.n;
+  const int n_mtiles = (n_rows + XM - 1) / XM, NTn = N / 32;
+  const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
+  hipLaunchKernelGGL(pn_gru_x3_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const uint4 *)h_oldS,
+                     (const uint4 *)Wp, (const uint4 *)Up, b, N, KTx, tps, act, tansig, h_new, (uint4 *)h_newS, n_rows,
+                     n_mtiles);
+}
+
+void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded) {
+  const size_t n = (size_t)n_rows_padded * (width >> 3);
+  hipLaunchKernelGGL(pn_split_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ld, width, (uint4 *)S,
+                     n_rows_padded);
+}

@@ -7,7 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
 model = api.Model(weights.default_blob(1234))
-MODE = {'f32': api.NN_MFMA, 'f16': api.NN_MFMA_F16, 'strict': api.NN_STRICT}[os.environ.get('PN_MODE', 'f32')]
+MODE = {'f32': api.NN_MFMA, 'f16': api.NN_MFMA_F16, 'strict': api.NN_STRICT, 'x3': api.NN_MFMA_X3}[os.environ.get('PN_MODE', 'f32')]
 ctx = api.Context(model, B, nn_mode=MODE, stream=torch.cuda.current_stream().cuda_stream)
 P = min(B, 64); T = K + 2
 pool = torch.from_numpy(synth.synth_batch(P, T)).to(dev)

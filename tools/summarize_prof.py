@@ -18,8 +18,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles"))
+ap.add_argument("--suffix", default="", help="configuration suffix of the output names: '' (headline), _1024, _fp16")
 a = ap.parse_args()
-SRC, out, tag = a.src, a.out, a.tag
+SRC, out, tag, suf = a.src, a.out, a.tag, a.suffix
 os.makedirs(out, exist_ok=True)
 import bench
 snap = bench.kernels_snapshot()
@@ -43,7 +44,7 @@ if os.path.exists(trace):
         d[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[key] = (r["Workgroup_Size_X"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
     tot = sum(sum(v) for v in d.values())
-    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out, f"{tag}_kernel_stats{suf}.csv"), "w") as f:
         f.write(f"# kernels_snapshot={snap}\n")
         w = csv.writer(f)
         w.writerow(["kernel", "grid", "calls", "total_ms", "avg_us", "pct", "min_us", "max_us", "wg", "lds", "vgpr", "agpr", "sgpr", "scratch"])
@@ -65,7 +66,7 @@ for sub in sorted(os.listdir(SRC)) if os.path.isdir(SRC) else []:
         key = f"{k} grid={r['Grid_Size']}"
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if agg:
-    with open(os.path.join(out, f"{tag}_pmc_per_launch.csv"), "w") as f:
+    with open(os.path.join(out, f"{tag}_pmc_per_launch{suf}.csv"), "w") as f:
         f.write(f"# kernels_snapshot={snap}\n")
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "launches", "avg", "min", "max"])
@@ -77,5 +78,5 @@ bj = os.path.join(SRC, "stats_bench.json")
 if os.path.exists(bj):
     txt = open(bj).read().strip()
     if txt:
-        open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write(txt + "\n")
+        open(os.path.join(out, f"{tag}_bench_under_rocprof{suf}.json"), "w").write(txt + "\n")
 print("wrote", sorted(x for x in os.listdir(out) if x.startswith(tag)))
