@@ -24,6 +24,7 @@
 //   Per wave and k-step of 16: 4 global loads, 2*NT ds_read_b128, 6*NT MFMAs of 32 cycles -> LDS reads take ~1/3 of
 //   the MFMA time on a CU (with 32-row wave tiles they would take 2/3, with A through LDS more than all of it).
 #include "pn_nn_common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float fvec4 __attribute__((ext_vector_type(4)));
@@ -38,7 +39,7 @@ struct X3Shared {
 #define X3_TLD 36                      // epilogue stage: 32 rows x 32 columns per wave, rows padded to 36 floats
 static_assert(4 * 32 * X3_TLD * sizeof(float) <= sizeof(uint4) * 2 * 4 * 4 * 64, "stage aliases the weight buffers");
 
-struct X3A { fvec4 h[2], l[2]; };      // one k-step of A fragments: [row group of 32] hi / lo
+template <int RG> struct X3A { fvec4 h[RG], l[RG]; };      // one k-step of A fragments: [row group of 32] hi / lo
 
 __device__ __forceinline__ half8 x3_h8(const fvec4 &v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ half8 x3_h8(const uint4 &v) { return __builtin_bit_cast(half8, v); }
@@ -57,27 +58,50 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], uint4 &hi, uint4 
 }
 
 // A fragments of k-step s (0/1) of the 32-k tile at pt (= plane-0 pointer of the lane; plane 1 is X3_PLANE further)
-__device__ __forceinline__ void x3_load_A(X3A &q, const uint4 *__restrict__ pt, int s) {
-  q.h[0] = *reinterpret_cast<const fvec4 *>(pt + s * 256);
-  q.h[1] = *reinterpret_cast<const fvec4 *>(pt + s * 256 + 32);
-  q.l[0] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256);
-  q.l[1] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256 + 32);
+template <int RG>
+__device__ __forceinline__ void x3_load_A(X3A<RG> &q, const uint4 *__restrict__ pt, int s) {
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) q.h[rg] = *reinterpret_cast<const fvec4 *>(pt + s * 256 + 32 * rg);
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) q.l[rg] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256 + 32 * rg);
 }
 
-// one k-step: acc[rg][IDX[t]] += A * B[t] for both row groups, three products each (small terms first)
-template <int NT, int I0, int I1, int I2, int I3>
-__device__ __forceinline__ void x3_kstep(const X3A &q, const uint4 (*Bs)[4][64], int s, int lane, floatx16 (&acc)[2][4]) {
+// one 32-k tile (two k-steps): acc[rg][IDX[t]] += A * B[t] for both row groups, three products each (small terms
+// first).  The B fragments of group (k-step, column tile) i+1 are read while the six MFMAs of group i run; the A
+// registers of a k-step are refilled (tile + 2) as soon as its last MFMA has issued — PF = the lane's pointer to that tile.
+struct X3B { fvec4 h, l; };
+__device__ __forceinline__ X3B x3_read_B(const uint4 (*Bs)[4][64], int t, int s, int lane) {
+  X3B f;
+  f.h = *reinterpret_cast<const fvec4 *>(&Bs[t][2 * s][lane]);
+  f.l = *reinterpret_cast<const fvec4 *>(&Bs[t][2 * s + 1][lane]);
+  return f;
+}
+template <int RG>
+__device__ __forceinline__ void x3_mma6(const X3A<RG> &q, const X3B &f, floatx16 (&acc)[RG][4], int idx) {
+  const half8 bh = x3_h8(f.h), bl = x3_h8(f.l);
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.l[rg]), bh, acc[rg][idx], 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bl, acc[rg][idx], 0, 0, 0);
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bh, acc[rg][idx], 0, 0, 0);
+}
+template <int RG, int NT, int I0, int I1, int I2, int I3>
+__device__ __forceinline__ void x3_tile(X3A<RG> &qa, X3A<RG> &qb, const uint4 (*Bs)[4][64], const uint4 *__restrict__ pf, int lane,
+                                        floatx16 (&acc)[RG][4]) {
   constexpr int IDX[4] = {I0, I1, I2, I3};
+  X3B f0 = x3_read_B(Bs, 0, 0, lane), f1;
 #pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const half8 bh = x3_h8(*reinterpret_cast<const fvec4 *>(&Bs[t][2 * s][lane])), bl = x3_h8(*reinterpret_cast<const fvec4 *>(&Bs[t][2 * s + 1][lane]));
-#pragma unroll
-    for (int rg = 0; rg < 2; rg++) {
-      floatx16 a = acc[rg][IDX[t]];
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.l[rg]), bh, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bl, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bh, a, 0, 0, 0);
-      acc[rg][IDX[t]] = a;
+  for (int i = 0; i < 2 * NT; i++) {
+    const int s = i / NT, t = i % NT;
+    X3B &cur = (i & 1) ? f1 : f0, &nxt = (i & 1) ? f0 : f1;
+    if (i + 1 < 2 * NT) nxt = x3_read_B(Bs, (i + 1) % NT, (i + 1) / NT, lane);
+    __builtin_amdgcn_sched_barrier(0);                   // keep the read ahead of the MFMAs it overlaps (the scheduler sinks it)
+    x3_mma6<RG>(s ? qb : qa, cur, acc, IDX[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == NT - 1) {
+      x3_load_A<RG>(s ? qb : qa, pf, s);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -124,8 +148,8 @@ __device__ __forceinline__ void x3_store_tile(float *T, const float (&v)[16], fl
 
 // ---- dense / conv layer: out = act(bias + A W), NT column tiles per block ----------------------------------------
 // A: shadow panels (PnSegs pointers carry uint4* shadows; width = logical columns of each panel, all equal)
-template <int NT>
-__global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_x3_kernel(
+template <int RG, int NT>
+__global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_dense_x3_kernel(
     PnSegs A, const uint4 *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
     const float *__restrict__ tansig, float *__restrict__ out, int ldo, uint4 *__restrict__ outS, int nts_out,
     int n_rows, int n_mtiles, int n_cblocks) {
@@ -134,16 +158,19 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_x3_kernel(
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
-  floatx16 acc[2][4];
+  floatx16 acc[RG][4];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const int col = (cb * NT + t) * 32 + (lane & 31);
     const float bv = col < N ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { acc[0][t][i] = bv; acc[1][t][i] = bv; }
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[rg][t][i] = bv;
   }
-  const int mt128 = 2 * mt + (wave >> 1);
-  const int lane_off = (lane >> 5) * 128 + 64 * (wave & 1) + (lane & 31);
+  constexpr int XMB = 128 * RG;                          // rows per block
+  const int mt128 = (mt * XMB + 32 * RG * wave) >> 7, srow = (32 * RG * wave) & 127;
+  const int lane_off = (lane >> 5) * 128 + srow + (lane & 31);
   const uint4 *wbase = Wp + (size_t)(cb * NT) * KT * 256;
   PN_PANEL_LOCALS(A);
   (void)pld;
@@ -159,22 +186,18 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_x3_kernel(
 #define XD_BLOAD(gg) do { int g_ = (gg); g_ = g_ < KT ? g_ : KT - 1; \
     _Pragma("unroll") for (int t = 0; t < NT; t++) X3_BLOAD(rb[t], wbase + ((size_t)t * KT + g_) * 256); } while (0)
 #define XD_BSTASH(buf) do { _Pragma("unroll") for (int t = 0; t < NT; t++) X3_BSTASH(buf, t, rb[t]); } while (0)
-  X3A q0, q1, q2, q3;
+  X3A<RG> q0, q1, q2, q3;
   fvec4 rb[NT];
-  { XD_APTR(0, p0); x3_load_A(q0, p0, 0); x3_load_A(q1, p0, 1); }
-  { XD_APTR(1, p1); x3_load_A(q2, p1, 0); x3_load_A(q3, p1, 1); }
+  { XD_APTR(0, p0); x3_load_A<RG>(q0, p0, 0); x3_load_A<RG>(q1, p0, 1); }
+  { XD_APTR(1, p1); x3_load_A<RG>(q2, p1, 0); x3_load_A<RG>(q3, p1, 1); }
   XD_BLOAD(0); XD_BSTASH(0); XD_BLOAD(1);
   __syncthreads();
 #pragma unroll 1
   for (int g = 0; g < KT; g += 2) {
-    { XD_APTR(g + 2, pa);
-      x3_kstep<NT, 0, 1, 2, 3>(q0, S.B[0], 0, lane, acc); x3_load_A(q0, pa, 0);
-      x3_kstep<NT, 0, 1, 2, 3>(q1, S.B[0], 1, lane, acc); x3_load_A(q1, pa, 1); }
+    { XD_APTR(g + 2, pa); x3_tile<RG, NT, 0, 1, 2, 3>(q0, q1, S.B[0], pa, lane, acc); }
     XD_BSTASH(1); XD_BLOAD(g + 2);
     __syncthreads();
-    { XD_APTR(g + 3, pb);
-      x3_kstep<NT, 0, 1, 2, 3>(q2, S.B[1], 0, lane, acc); x3_load_A(q2, pb, 0);
-      x3_kstep<NT, 0, 1, 2, 3>(q3, S.B[1], 1, lane, acc); x3_load_A(q3, pb, 1); }
+    { XD_APTR(g + 3, pb); x3_tile<RG, NT, 0, 1, 2, 3>(q2, q3, S.B[1], pb, lane, acc); }
     XD_BSTASH(0); XD_BLOAD(g + 3);
     __syncthreads();
   }
@@ -187,18 +210,30 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_x3_kernel(
     const int ct = cb * NT + t, col0 = ct * 32;
     if (col0 >= N) break;
 #pragma unroll
-    for (int rg = 0; rg < 2; rg++) {
+    for (int rg = 0; rg < RG; rg++) {
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) v[i] = pn_act(acc[rg][t][i], act, S.tansig);
       uint4 *Sx = outS ? outS + ((size_t)mt128 * nts_out + ct) * (2 * X3_PLANE) : nullptr;
-      x3_store_tile(T, v, out, ldo, col0, N, mt * XM + 64 * wave + 32 * rg, n_rows, Sx, 64 * (wave & 1) + 32 * rg, lane);
+      x3_store_tile(T, v, out, ldo, col0, N, mt * XMB + 32 * RG * wave + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
     }
   }
 }
 
+// Tuning aid (-DPN_X3_CLOCKS): shader-clock stamps of wave 0 of every block of the last N=512 launch
+#ifdef PN_X3_CLOCKS
+__device__ unsigned long long pn_x3_trace[4096 * 8];
+extern "C" int pn_x3_trace_read(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3_trace), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#define X3_STAMP(i) do { if (N == 512) ck_[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X3_STAMP(i) do { } while (0)
+#endif
+
 // ---- GRU step (reset-after, nnet.cpp:122-180): acc z, r, hx (W_h x), tmp (U_h h) ---------------------------------
-__global__ __launch_bounds__(NN_THREADS, 2) void pn_gru_x3_kernel(
+template <int RG>
+__global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_x3_kernel(
     PnSegs X, const float *__restrict__ h_old, const uint4 *__restrict__ h_oldS, const uint4 *__restrict__ Wp,
     const uint4 *__restrict__ Up, const float *__restrict__ b, int N, int KTx, int tps, int act,
     const float *__restrict__ tansig, float *__restrict__ h_new, uint4 *__restrict__ h_newS, int n_rows, int n_mtiles) {
@@ -206,22 +241,28 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_gru_x3_kernel(
   const int NTn = N >> 5;
   int mt, nt;
   if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
+#ifdef PN_X3_CLOCKS
+  unsigned long long ck_[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long w0_ = wall_clock64();
+  X3_STAMP(0);
+#endif
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int KTh = NTn, T1 = KTx, TT = KTx + KTh;
   const int col = nt * 32 + (lane & 31);
   for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
-  floatx16 acc[2][4];
+  floatx16 acc[RG][4];
   {
     float bz = b[col]; bz += b[3 * N + col];
     float br = b[N + col]; br += b[4 * N + col];
     const float bt = b[5 * N + col];
 #pragma unroll
-    for (int rg = 0; rg < 2; rg++)
+    for (int rg = 0; rg < RG; rg++)
 #pragma unroll
       for (int i = 0; i < 16; i++) { acc[rg][0][i] = bz; acc[rg][1][i] = br; acc[rg][2][i] = 0.f; acc[rg][3][i] = bt; }
   }
-  const int mt128 = 2 * mt + (wave >> 1);
-  const int lane_off = (lane >> 5) * 128 + 64 * (wave & 1) + (lane & 31);
+  constexpr int XMB = 128 * RG;                          // rows per block
+  const int mt128 = (mt * XMB + 32 * RG * wave) >> 7, srow = (32 * RG * wave) & 127;
+  const int lane_off = (lane >> 5) * 128 + srow + (lane & 31);
   const uint4 *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 256, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 256,
               *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 256;
   const uint4 *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 256, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 256,
@@ -246,26 +287,25 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_gru_x3_kernel(
     X3_BLOAD(rb[2], p1_ ? Wh + (size_t)kx_ * 256 : Uh + (size_t)kh_ * 256); } while (0)
 #define XG_BSTASH(buf) do { X3_BSTASH(buf, 0, rb[0]); X3_BSTASH(buf, 1, rb[1]); X3_BSTASH(buf, 2, rb[2]); } while (0)
 #define XG_PAIR(g, I2)                                                                                   \
-    { XG_APTR((g) + 2, pa);                                                                              \
-      x3_kstep<3, 0, 1, I2, 0>(q0, S.B[0], 0, lane, acc); x3_load_A(q0, pa, 0);                          \
-      x3_kstep<3, 0, 1, I2, 0>(q1, S.B[0], 1, lane, acc); x3_load_A(q1, pa, 1); }                        \
+    { XG_APTR((g) + 2, pa); x3_tile<RG, 3, 0, 1, I2, 0>(q0, q1, S.B[0], pa, lane, acc); }                    \
     XG_BSTASH(1); XG_BLOAD((g) + 2);                                                                     \
     __syncthreads();                                                                                     \
-    { XG_APTR((g) + 3, pb);                                                                              \
-      x3_kstep<3, 0, 1, I2, 0>(q2, S.B[1], 0, lane, acc); x3_load_A(q2, pb, 0);                          \
-      x3_kstep<3, 0, 1, I2, 0>(q3, S.B[1], 1, lane, acc); x3_load_A(q3, pb, 1); }                        \
+    { XG_APTR((g) + 3, pb); x3_tile<RG, 3, 0, 1, I2, 0>(q2, q3, S.B[1], pb, lane, acc); }                    \
     XG_BSTASH(0); XG_BLOAD((g) + 3);                                                                     \
     __syncthreads()
-  X3A q0, q1, q2, q3;
+  X3A<RG> q0, q1, q2, q3;
   fvec4 rb[3];
-  { XG_APTR(0, p0); x3_load_A(q0, p0, 0); x3_load_A(q1, p0, 1); }
-  { XG_APTR(1, p1); x3_load_A(q2, p1, 0); x3_load_A(q3, p1, 1); }
+  { XG_APTR(0, p0); x3_load_A<RG>(q0, p0, 0); x3_load_A<RG>(q1, p0, 1); }
+  { XG_APTR(1, p1); x3_load_A<RG>(q2, p1, 0); x3_load_A<RG>(q3, p1, 1); }
   XG_BLOAD(0); XG_BSTASH(0); XG_BLOAD(1);
   __syncthreads();
+  X3_STAMP(1);
 #pragma unroll 1
   for (int g = 0; g < T1; g += 2) { XG_PAIR(g, 2); }
+  X3_STAMP(2);
 #pragma unroll 1
   for (int g = T1; g < TT; g += 2) { XG_PAIR(g, 3); }
+  X3_STAMP(3);
 #undef XG_PAIR
 #undef XG_BSTASH
 #undef XG_BLOAD
@@ -276,15 +316,23 @@ __global__ __launch_bounds__(NN_THREADS, 2) void pn_gru_x3_kernel(
     float *T = reinterpret_cast<float *>(&S.B[0][0][0][0]) + wave * 32 * X3_TLD;
     uint4 *Sx = h_newS ? h_newS + ((size_t)mt128 * NTn + nt) * (2 * X3_PLANE) : nullptr;
 #pragma unroll
-    for (int rg = 0; rg < 2; rg++) {
-      const int grow0 = mt * XM + 64 * wave + 32 * rg;
+    for (int rg = 0; rg < RG; rg++) {
+      const int grow0 = mt * XMB + 32 * RG * wave + 32 * rg;
       float ho[16], v[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) ho[i] = h_old[(size_t)(grow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
       pn_gru_gate16(acc[rg][0], acc[rg][1], acc[rg][2], acc[rg][3], ho, bh, act, S.tansig, v);
-      x3_store_tile(T, v, h_new, N, nt * 32, N, grow0, n_rows, Sx, 64 * (wave & 1) + 32 * rg, lane);
+      x3_store_tile(T, v, h_new, N, nt * 32, N, grow0, n_rows, Sx, srow + 32 * rg, lane);
     }
   }
+#ifdef PN_X3_CLOCKS
+  X3_STAMP(4);
+  if (tid == 0 && N == 512 && blockIdx.x < 4096) {
+    unsigned long long *t = pn_x3_trace + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; i++) t[i] = ck_[i];
+    t[5] = wall_clock64(); t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[7] = w0_;
+  }
+#endif
 }
 
 // ---- fp32 rows -> fragment-order hi/lo shadow (the first layer's output; RNN state loaded from the host) ---------
@@ -337,31 +385,46 @@ int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_rou
 
 int pn_dense_x3_nt(int N) { return N >= 128 ? 4 : 2; }
 
+// rows per wave: 2 row groups of 32 (256-row blocks, two per CU) or 1 (128-row blocks, three per CU)
+static int x3_rg() {
+  static const int rg = getenv("PERCEPNET_X3_RG") ? atoi(getenv("PERCEPNET_X3_RG")) : 2;
+  return rg == 1 ? 1 : 2;
+}
+
 // A: panels carry the uint4* shadows of equally wide buffers (width = logical columns, a multiple of 32);
 // out (fp32, optional) / outS (shadow of a buffer nts_out column tiles wide, optional)
 void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
                         const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows) {
   const int tps = A.width[0] / 32, KT = tps * A.n;
   const int NT = pn_dense_x3_nt(N);
-  const int n_mtiles = (n_rows + XM - 1) / XM;
+  const int rg = x3_rg();
+  const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg);
   const int n_cblocks = x3_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
-#define XD_LAUNCH(NT_)                                                                                          \
-  hipLaunchKernelGGL((pn_dense_x3_kernel<NT_>), dim3(grid), dim3(NN_THREADS), 0, st, A, (const uint4 *)Wp, bias, N, \
+#define XD_LAUNCH(NT_) do { if (rg == 2) XD_LAUNCH2(2, NT_); else XD_LAUNCH2(1, NT_); } while (0)
+#define XD_LAUNCH2(RG_, NT_)                                                                                     \
+  hipLaunchKernelGGL((pn_dense_x3_kernel<RG_, NT_>), dim3(grid), dim3(NN_THREADS), 0, st, A, (const uint4 *)Wp, bias, N, \
                      KT, tps, act, tansig, out, ldo, (uint4 *)outS, nts_out, n_rows, n_mtiles, n_cblocks)
   if (NT == 4) XD_LAUNCH(4); else XD_LAUNCH(2);
 #undef XD_LAUNCH
+#undef XD_LAUNCH2
 }
 
 void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
                       int n_rows) {
   const int tps = X.width[0] / 32, KTx = tps * X.n;
-  const int n_mtiles = (n_rows + XM - 1) / XM, NTn = N / 32;
+  const int rg = x3_rg();
+  const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg), NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-  hipLaunchKernelGGL(pn_gru_x3_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const uint4 *)h_oldS,
-                     (const uint4 *)Wp, (const uint4 *)Up, b, N, KTx, tps, act, tansig, h_new, (uint4 *)h_newS, n_rows,
-                     n_mtiles);
+  if (rg == 2)
+    hipLaunchKernelGGL(pn_gru_x3_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const uint4 *)h_oldS,
+                       (const uint4 *)Wp, (const uint4 *)Up, b, N, KTx, tps, act, tansig, h_new, (uint4 *)h_newS, n_rows,
+                       n_mtiles);
+  else
+    hipLaunchKernelGGL(pn_gru_x3_kernel<1>, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, (const uint4 *)h_oldS,
+                       (const uint4 *)Wp, (const uint4 *)Up, b, N, KTx, tps, act, tansig, h_new, (uint4 *)h_newS, n_rows,
+                       n_mtiles);
 }
 
 void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded) {

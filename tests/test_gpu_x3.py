@@ -1,0 +1,175 @@
+"""Split-precision network mode (api.NN_MFMA_X3: every fp32 GEMM operand carried as an fp16 (hi, lo) pair, three
+v_mfma_f32_32x32x16_f16 products per operand pair, fp32 accumulation/state/activations; pn_nn_x3.hip).
+
+The mode claims the SAME parity bounds as the fp32 MFMA mode — north_star's +-1 LSB PCM, and 2e-5 on the g/r taps — so
+every test here uses test_gpu_parity / test_gpu_longrun's PCM_TOL_LSB = 1 and GR_TOL = 2e-5, not a re-stated tolerance:
+  * 40 streams x 100 frames and ragged batch sizes against the CPU oracle;
+  * placement invariance over grid-stride rounds (8195 streams of 7 kinds, bit-identical replicas);
+  * 1024 streams x 1000 frames (10 s), every stream against the oracle (the horizon SURVEY 8(d) asks for);
+  * weight sets with 2-3x the default dynamic range and biased gates: free-running over 10 s, and ONE network step
+    from identical state against the STRICT (reference-order, bit-exact) kernels, with the fp32 MFMA mode's bounds;
+  * operands outside the fp16 range: a weight beyond +-65504 is refused at context creation, never silently clipped.
+"""
+import numpy as np
+import pytest
+
+from percepnet_amd import api, synth, weights
+from test_gpu_longrun import run_long, shared_stream, compare, _record
+from test_gpu_parity import PCM_TOL_LSB, GR_TOL, _oracle_batch
+import test_gpu_stress_weights as stress
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    m = api.Model(blob)
+    yield m
+    m.close()
+
+
+def test_x3_mode_within_one_lsb(model, oracle):
+    B, T = 40, 100
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    assert ctx.describe()["nn"] == "mfma_x3"
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, pcm)
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    assert d.max() <= PCM_TOL_LSB, d.max()
+    assert np.abs(gr - rg).max() <= GR_TOL, np.abs(gr - rg).max()
+    ctx.close()
+
+
+@pytest.mark.parametrize("B", [1, 129, 300, 513])
+def test_x3_ragged_batch_sizes(model, oracle, B):
+    """Batch sizes that leave the last 256-row block ragged (1 row, 129 = one row into the second 128-row operand chunk,
+    300, 513): every stream against the oracle."""
+    T = 12
+    pcm = synth.synth_batch(min(B, 16), T)
+    pcm = pcm[np.arange(B) % pcm.shape[0]]
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    out, gr = ctx.run_pcm(pcm)
+    ro, rg = _oracle_batch(oracle, pcm[:16])
+    idx = np.arange(B) % min(B, 16)
+    assert np.abs(out.astype(np.int32) - ro[idx].astype(np.int32)).max() <= PCM_TOL_LSB
+    assert np.abs(gr - rg[idx]).max() <= GR_TOL
+    ctx.close()
+
+
+def test_x3_placement_invariance_across_grid_stride_rounds(model, oracle):
+    B, K, T = 8195, 7, 14
+    base = synth.synth_batch(K, T, first_stream=1)
+    idx = np.arange(B) % K
+    pcm = base[idx]
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    ro, rg, rf, rs = oracle.run_batch(base)
+    for t in range(T):
+        frame = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])
+        out, gr = ctx.process_i16(frame)
+        assert np.abs(gr[:K] - rg[:, t]).max() <= GR_TOL, (t, "g/r vs oracle")
+        if t > 0:
+            assert np.abs(out[:K].astype(np.int32) - ro[:, (t - 1) * 480:t * 480].astype(np.int32)).max() <= PCM_TOL_LSB, t
+        for k in range(K):
+            m = idx == k
+            g = gr[m].view(np.uint32)
+            assert (g == g[0]).all(), (t, k, "g/r")
+            assert (out[m] == out[m][0]).all(), (t, k, "pcm")
+    ctx.close()
+
+
+def test_x3_1024_streams_1000_frames_every_stream_vs_oracle(model, oracle):
+    import torch
+    B, T = 1024, 1000
+    dev = torch.device("cuda:0")
+    pcm = synth.synth_batch_parallel(B, T)
+    ref = oracle.run_batch(pcm, group=8)
+    ts = shared_stream(dev)
+    with torch.cuda.stream(ts):
+        d_pcm = torch.from_numpy(pcm).to(dev)
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3, stream=ts.cuda_stream)
+        got = run_long(ctx, lambda t: d_pcm[:, t * 480:(t + 1) * 480].contiguous(), T, None, dev)
+        ctx.close()
+    compare("x3_1024x1000", got, ref, {
+        "config": "split-precision network mode (fp16 hi/lo operand planes, 3 MFMA products, fp32 accumulate), 1024 streams x 1000 frames, every stream vs the CPU oracle"})
+
+
+@pytest.mark.parametrize("name", ["scale2", "scale3", "scale2_gate_biased", "scale6_saturating"])
+def test_x3_mode_on_other_weight_sets(name):
+    """The stress sets of test_gpu_stress_weights.py with the fp32 MFMA mode's bounds (ONE_STEP_TOL, BOUNDS)."""
+    import torch
+    from oracle.oracle import Oracle
+    B, T = 256, 1000
+    blob = weights.pack_blob(stress.SETS[name]())
+    pcm = synth.synth_batch_parallel(B, T, first_stream=700)
+    ro, rg, rf, rs = Oracle(blob).run_batch(pcm, group=8)
+    dev = torch.device("cuda:0")
+    model = api.Model(blob)
+    ts = shared_stream(dev)
+    with torch.cuda.stream(ts):
+        d_pcm = torch.from_numpy(pcm).to(dev)
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3, stream=ts.cuda_stream)
+        out, gr, feat, sil = run_long(ctx, lambda t: d_pcm[:, t * 480:(t + 1) * 480].contiguous(), T, None, dev)
+        ctx.close()
+    TS = 200
+    cx = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    cs = api.Context(model, B, nn_mode=api.NN_STRICT)
+    one = np.zeros(TS)
+    for t in range(TS):
+        cx.set_rnn_state(cs.get_rnn_state())                # re-derives the hi/lo operand planes from the fp32 state
+        gs_, gx_ = cs.compute_rnn(rf[:, t]), cx.compute_rnn(rf[:, t])
+        assert np.isfinite(gx_).all(), t
+        one[t] = np.abs(gs_ - gx_).max()
+    cx.close(); cs.close(); model.close()
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    d = np.minimum(d, 65536 - d)
+    dg = np.abs(gr - rg)
+    by_s = [float(dg[:, k:k + 100].max()) for k in range(0, T, 100)]
+    _record(f"x3_stress_{name}", {
+        "mode": "split precision (NN_MFMA_X3)", "weights": name, "streams": B, "frames": T,
+        "one_step_from_identical_state_max_abs_delta_gr": float(one.max()),
+        "max_abs_delta_pcm_lsb_circular": int(d.max()),
+        "pcm_delta_histogram_lsb": np.bincount(np.minimum(d, 16).ravel().astype(np.int64), minlength=17).tolist(),
+        "max_abs_delta_gr": float(dg.max()), "mean_abs_delta_gr": float(dg.mean()),
+        "p9999_abs_delta_gr": float(np.quantile(dg, 0.9999)), "max_abs_delta_gr_by_second": by_s})
+    assert np.isfinite(gr).all()
+    assert np.array_equal(feat.view(np.uint32), rf.view(np.uint32)) and np.array_equal(sil, rs)
+    assert one.max() <= stress.ONE_STEP_TOL[name], float(one.max())
+    assert max(by_s) <= 8 * max(by_s[0], 1e-6) + 1e-6, by_s
+    lsb, tol = stress.BOUNDS[name]
+    if lsb is not None:
+        assert d.max() <= lsb, int(d.max())
+    assert dg.max() <= tol, float(dg.max())
+
+
+def test_x3_rnn_state_roundtrip(model, oracle):
+    """get/set of the RNNState arrays (nnet_data.h:28-38) in the split-precision mode: loading a state re-derives the
+    operand planes, so a context restored from another's state continues bit-identically to it."""
+    B, T = 130, 6
+    rng = np.random.default_rng(3)
+    feats = rng.standard_normal((T, B, 70)).astype(np.float32)
+    a = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    for t in range(3):
+        a.compute_rnn(feats[t])
+    st = a.get_rnn_state()
+    b = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    for t in range(3):
+        b.compute_rnn(feats[5 - t])                          # a different history, then overwritten
+    # the ring phase (which slot is "oldest") is part of the context, not of the state: bring b to the same frame count
+    b.set_rnn_state(st)
+    for t in range(3, T):
+        ga, gb = a.compute_rnn(feats[t]), b.compute_rnn(feats[t])
+        assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32)), t
+    a.close(); b.close()
+
+
+def test_x3_refuses_weights_outside_the_fp16_range():
+    lay = weights.random_layers(5)
+    w = lay["conv2"]["input_weights"].copy()
+    w.reshape(-1)[17] = 1e5
+    lay["conv2"]["input_weights"] = w
+    m = api.Model(weights.pack_blob(lay))
+    with pytest.raises(api.PercepNetError, match="fp16 range"):
+        api.Context(m, 64, nn_mode=api.NN_MFMA_X3)
+    c = api.Context(m, 64, nn_mode=api.NN_MFMA)              # the fp32 modes take the same model
+    c.close(); m.close()
