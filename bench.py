@@ -218,16 +218,22 @@ def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
         return None
     avg_s = ms / n * 1e-3
     flops = B * GRU512_FLOP_PER_STREAM_FRAME
-    kname = "pn_gru_f16_kernel" if fp16 else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel")
+    x3 = desc.get("nn") == "mfma_x3"
+    kname = "pn_gru_x3_kernel" if x3 else ("pn_gru_f16_kernel" if fp16 else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel"))
     traffic, traffic_src = pmc_traffic_bytes(B, kname[:11], traffic_tag)
     ach = flops / avg_s / 1e12
-    peak = 2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS      # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
+    # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md).  Split precision: `achieved` stays the ALGORITHMIC rate (2 M N K per
+    # launch); every product costs three fp16 MFMAs, so the bound is a third of the dense fp16 peak
+    peak = round(2500.0 / 3, 1) if x3 else (2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS)
     r = {"kernel": kname + " (512->512 reset-after GRU step, 4 launches per frame)",
          "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": traffic,
          "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
-         "algorithmic_bytes_per_launch": 3 * B * 512 * (2 if fp16 else 4) + (B * 512 * 4 if fp16 else 0) + 2 * 512 * 1536 * (2 if fp16 else 4),
+         "algorithmic_bytes_per_launch": 3 * B * 512 * (2 if fp16 else 4) + (B * 512 * 4 if (fp16 or x3) else 0) + 2 * 512 * 1536 * (2 if fp16 else 4),
          "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4)}
+    if x3:
+        r["peak_note"] = ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (three fp16 MFMA products per fp32 product); executed MFMA rate = "
+                          f"{round(3 * ach, 1)} TFLOP/s; the fp32 MFMA peak this replaces is {PEAK_FP32_MFMA_TFLOPS} TFLOP/s")
     if fps is not None:
         r["whole_pipeline_tflops"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2)
         r["whole_pipeline_frac_of_mfma_peak"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / peak, 4)
@@ -307,8 +313,13 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
             "pcm_samples_checked": par["pcm_samples_checked"], "replay_bit_identical": par["replay_of_timed_run_bit_identical"],
             "kernel_families": desc,
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
+            "dtype": DTYPE_OF_MODE[nn_mode],
             "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, traffic_tag=traffic_tag),
             "dsp_roofline": dsp_roofline(kt, B)}
+
+
+DTYPE_OF_MODE = {0: "f32", 1: "f32 (reference order, separate mul/add)", 2: "f16 GEMM operands, f32 accumulate/state/DSP",
+                 3: "f32 carried as fp16 hi+lo operand pairs (3 fp16 MFMA products per fp32 product), f32 accumulate/state/DSP"}
 
 
 def drop_in_single_stream(frames=1000):
@@ -360,6 +371,9 @@ def main():
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
     ap.add_argument("--fp16", action="store_true",
                     help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: <=3 LSB)")
+    ap.add_argument("--x3", action="store_true",
+                    help="split-precision network mode (PN_NN_MFMA_X3): fp32 operands as fp16 hi+lo pairs, 3 fp16 MFMA products, "
+                         "fp32 accumulate; same parity bounds as the fp32 MFMA mode (tests/test_gpu_x3.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 through torch.distributed.run too: the RCCL init, barriers, all-reduces and gather of the N > 1 path")
@@ -409,7 +423,7 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    ctx = api.Context(model, B, device=local_rank, nn_mode=api.NN_STRICT if a.strict else (api.NN_MFMA_F16 if a.fp16 else api.NN_MFMA),
+    ctx = api.Context(model, B, device=local_rank, nn_mode=api.NN_STRICT if a.strict else (api.NN_MFMA_F16 if a.fp16 else (api.NN_MFMA_X3 if a.x3 else api.NN_MFMA)),
                       stream=stream.cuda_stream)
 
     # synthetic input, resident in HBM: a pool of 64 distinct streams (voiced / bursts+silence /
@@ -469,13 +483,13 @@ def main():
             "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 GEMM operands, f32 accumulate/state/DSP" if a.fp16 else "f32", "data": "synthetic",
+            "dtype": DTYPE_OF_MODE[1 if a.strict else (2 if a.fp16 else (3 if a.x3 else 0))], "data": "synthetic",
             "config": {
                 "workload": ("configs[2]: 65536 concurrent 48 kHz streams per MI355X, fp32 network as MFMA GEMM"
-                             if (B == 65536 and not a.fp16) else
-                             ("configs[4]: fp16 weights/activations variant, " if a.fp16 else "") +
+                             if (B == 65536 and not a.fp16 and not a.x3) else
+                             ("configs[4]: fp16 weights/activations variant, " if a.fp16 else ("split-precision network mode, " if a.x3 else "")) +
                              f"{B} concurrent 48 kHz streams per MI355X (configs[1] = 1024)"),
-                "streams_per_gpu": B, "frame_samples": FRAME, "nn_mode": "strict" if a.strict else ("mfma_f16" if a.fp16 else "mfma_f32"),
+                "streams_per_gpu": B, "frame_samples": FRAME, "nn_mode": "strict" if a.strict else ("mfma_f16" if a.fp16 else ("mfma_x3" if a.x3 else "mfma_f32")),
                 "weights": "torch.manual_seed(1234) default-init PercepNet in nnet_data.h layout",
                 "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective",
                 "io": "int16 PCM resident in HBM",
@@ -494,7 +508,7 @@ def main():
         if kt:
             per = {k: {"ms_avg": round(v[0] / max(v[1], 1), 4), "launches": v[1]} for k, v in kt.items()}
             res["kernels"] = per
-            tag = "_fp16" if a.fp16 else ("" if B == 65536 else f"_{B}")
+            tag = "_fp16" if a.fp16 else ("_x3" if a.x3 else ("" if B == 65536 else f"_{B}"))
             rl = gru_roofline(kt, B, a.fp16, desc, n_gpus, fps, traffic_tag=tag)
             if rl:
                 res["roofline"] = rl
@@ -522,11 +536,14 @@ def main():
         # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
         # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
         # Only with the default headline workload at N = 1; a failure here never costs the headline line.
-        if world == 1 and B == 65536 and not (a.fp16 or a.strict or a.no_other_configs or a.no_parity):
+        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_other_configs or a.no_parity):
             other = {}
             for key, (b2, k2, w2, mode2, label, ttag) in {
                     "configs[1]": (1024, 200, 20, api.NN_MFMA, "1024 concurrent streams, fp32 (small-batch kernel family)", "_1024"),
                     "configs[4]": (65536, 20, 3, api.NN_MFMA_F16, "65536 concurrent streams, fp16 GEMM operands, fp32 accumulate/state/DSP", "_fp16"),
+                    # not a BASELINE config: the same fp32 network evaluated on the fp16 matrix cores with error compensation,
+                    # inside the fp32 MFMA mode's parity bounds (tests/test_gpu_x3.py); opt-in (`--x3`), never the headline `value`
+                    "split_precision_x3": (65536, 20, 3, api.NN_MFMA_X3, "65536 concurrent streams, fp32 network as fp16 hi+lo operand pairs (3 MFMA products), fp32 accumulate/state/DSP", "_x3"),
             }.items():
                 try:
                     other[key] = side_config(api, synth, torch, model, dev, stream, b2, k2, w2, mode2, label, ttag)

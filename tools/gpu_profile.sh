@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for the bench command, then the summaries.
-#   tools/gpu_profile.sh <tag> [suffix] [extra bench args]     suffix: "" (headline), _1024, _fp16 -> <tag>_kernel_stats<suffix>.csv ...
+#   tools/gpu_profile.sh <tag> [suffix] [extra bench args]     suffix: "" (headline), _1024, _fp16, _x3 -> <tag>_kernel_stats<suffix>.csv ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03}; shift
 SUF=""; case "$1" in _*) SUF=$1; shift;; esac

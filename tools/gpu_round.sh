@@ -12,8 +12,10 @@ fi
 timeout 600 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err; tail -c 600 $O/bench_$TAG.err
 timeout 300 python bench.py --streams 1024 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_${TAG}_1024.json 2>> $O/bench_$TAG.err
 timeout 300 python bench.py --fp16 --no-cpu-baseline > $O/bench_${TAG}_fp16.json 2>> $O/bench_$TAG.err
+timeout 300 python bench.py --x3 --no-cpu-baseline > $O/bench_${TAG}_x3.json 2>> $O/bench_$TAG.err
 timeout 900 bash tools/gpu_profile.sh $TAG > $O/profile_$TAG.log 2>&1
 timeout 600 bash tools/gpu_profile.sh $TAG _1024 --streams 1024 --steps 100 >> $O/profile_$TAG.log 2>&1
 timeout 600 bash tools/gpu_profile.sh $TAG _fp16 --fp16 >> $O/profile_$TAG.log 2>&1
+timeout 600 bash tools/gpu_profile.sh $TAG _x3 --x3 >> $O/profile_$TAG.log 2>&1
 head -c 1500 $O/bench_$TAG.json; echo
 ls $O/prof_summary

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles"))
-ap.add_argument("--suffix", default="", help="configuration suffix of the output names: '' (headline), _1024, _fp16")
+ap.add_argument("--suffix", default="", help="configuration suffix of the output names: '' (headline), _1024, _fp16, _x3")
 a = ap.parse_args()
 SRC, out, tag, suf = a.src, a.out, a.tag, a.suffix
 os.makedirs(out, exist_ok=True)
