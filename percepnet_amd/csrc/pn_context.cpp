@@ -205,7 +205,7 @@ static int upload(pn_ctx *c, float **dst, const float *src, size_t n) {
 
 // operand shadows: 1 half per element (fp16-operand mode) or a hi and a lo plane (split-precision mode)
 static size_t shadow_halfs_per_element(const pn_ctx *c) { return c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1; }
-static bool x3_layer(int li) { return li == PN_L_CONV1 || li == PN_L_CONV2 || li == PN_L_GRU_RB || (li >= PN_L_GRU1 && li < PN_L_GRU1 + 4); }
+static bool x3_layer(int li) { return li == PN_L_CONV1 || li == PN_L_CONV2 || li == PN_L_GRU_RB || li == PN_L_FC_GB || (li >= PN_L_GRU1 && li < PN_L_GRU1 + 4); }
 static int zero_state(pn_ctx *c) {
   const size_t B = c->B;
   PN_HIP_CHECK(hipMemsetAsync(c->hist, 0, B * PN_HIST_STRIDE * 4, c->stream));
@@ -355,7 +355,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
       const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
       const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
       const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
-      if (nn_mode == PN_NN_MFMA_X3 && x3_layer(li)) {      // conv1, conv2 and the GRUs; fc / fc_gb / fc_rb stay fp32 below
+      if (nn_mode == PN_NN_MFMA_X3 && x3_layer(li)) {      // conv1, conv2, the GRUs and fc_gb; fc and fc_rb (K = 70 / 128) stay fp32 below
         const int ctx3 = H.kind == PN_KIND_GRU ? 1 : pn_dense_x3_nt(H.nn);
         std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3));
         if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the split-precision mode cannot represent it", li); goto fail; }
@@ -546,7 +546,8 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
+    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
     else if (c->L[PN_L_FC_GB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
   { Scope sc(c, KF_FC_RB);
