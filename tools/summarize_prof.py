@@ -28,6 +28,14 @@ snap = bench.kernels_snapshot()
 
 def short(name):
     n = name.replace("void ", "")
+    if n.startswith("_Z"):                      # left mangled by rocprofv3 (it cannot demangle _Float16 parameters): _Z<len><name>[I<template args>E]...
+        import re
+        m = re.match(r"_Z(\d+)", n)
+        if m:
+            ln = int(m.group(1)); base = n[m.end():m.end() + ln]; rest = n[m.end() + ln:]
+            t = re.match(r"I((?:L[bi]\d+E)+)E", rest)
+            targs = "<" + ",".join(x[1:] for x in re.findall(r"L([bi]\d+)E", t.group(1))) + ">" if t else ""
+            return base + targs
     return n.split("(")[0]
 
 
