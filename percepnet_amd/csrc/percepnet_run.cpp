@@ -4,7 +4,7 @@
 // mono 48 kHz in; (frames-1)*480 samples out (first output frame dropped, main.cpp:37; partial tail frame
 // dropped, main.cpp:32-33); with a single pair ./feature_test.raw gets 68 floats per frame.
 //
-//   percepnet_run [--model model.pnw] [--strict] [--postfilter] [--device N | --devices 0,1,..|all]
+//   percepnet_run [--model model.pnw] [--strict | --x3] [--postfilter] [--device N | --devices 0,1,..|all]
 //                 in0.pcm out0.pcm [in1.pcm out1.pcm ...]
 //
 // Multi-GPU: streams are independent, so the pairs are cut into contiguous balanced shards, one per
@@ -40,11 +40,11 @@ struct ShardRes {
 };
 
 // One device: pairs [first, first+count) of argv-style (in, out) paths as `count` concurrent streams.
-static void run_shard(Shard *sh, const pn_model *m, char **paths, int strict, int postfilter, bool tap) {
+static void run_shard(Shard *sh, const pn_model *m, char **paths, int nn_mode, int postfilter, bool tap) {
   const int B = sh->count;
   auto fail = [&](int rc, const std::string &msg) { sh->rc = rc; sh->err = msg; };
   ShardRes R;
-  R.cx = pn_ctx_create(m, sh->device, B, strict ? PN_NN_STRICT : PN_NN_MFMA, NULL);
+  R.cx = pn_ctx_create(m, sh->device, B, nn_mode, NULL);
   pn_ctx *cx = R.cx;
   if (!cx) return fail(3, std::string("pn_ctx_create: ") + pn_last_error());
   if (postfilter) pn_ctx_set_postfilter(cx, 1);
@@ -98,11 +98,12 @@ static void run_shard(Shard *sh, const pn_model *m, char **paths, int strict, in
 
 int main(int argc, char **argv) {
   const char *model_path = getenv("PERCEPNET_MODEL");
-  int strict = 0, postfilter = 0, ai = 1;
+  int nn_mode = PN_NN_MFMA, postfilter = 0, ai = 1;
   std::vector<int> devices;
   for (; ai < argc; ai++) {
     if (!strcmp(argv[ai], "--model") && ai + 1 < argc) model_path = argv[++ai];
-    else if (!strcmp(argv[ai], "--strict")) strict = 1;
+    else if (!strcmp(argv[ai], "--strict")) nn_mode = PN_NN_STRICT;      // reference-order network, bit-exact to the CPU path
+    else if (!strcmp(argv[ai], "--x3")) nn_mode = PN_NN_MFMA_X3;         // split-precision network (same +-1 LSB bound, ~2x the rate)
     else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
     else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) devices.assign(1, atoi(argv[++ai]));
     else if (!strcmp(argv[ai], "--devices") && ai + 1 < argc) {
@@ -116,7 +117,7 @@ int main(int argc, char **argv) {
   if (devices.empty()) devices.push_back(0);
   const int nfiles = argc - ai;
   if (nfiles < 2 || (nfiles & 1)) {
-    fprintf(stderr, "usage: %s [--model model.pnw] [--strict] [--postfilter] [--device N | --devices 0,1,..|all] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
+    fprintf(stderr, "usage: %s [--model model.pnw] [--strict | --x3] [--postfilter] [--device N | --devices 0,1,..|all] <noisy speech> <output denoised> [...more pairs]\n", argv[0]);
     return 1;
   }
   const int B = nfiles / 2;
@@ -134,10 +135,10 @@ int main(int argc, char **argv) {
     shards[r] = {devices[r], first, count, 0, ""};
   }
   const bool tap = B == 1;
-  if (W == 1) run_shard(&shards[0], m, argv + ai, strict, postfilter, tap);
+  if (W == 1) run_shard(&shards[0], m, argv + ai, nn_mode, postfilter, tap);
   else {
     std::vector<std::thread> th;
-    for (int r = 0; r < W; r++) th.emplace_back(run_shard, &shards[r], m, argv + ai, strict, postfilter, false);
+    for (int r = 0; r < W; r++) th.emplace_back(run_shard, &shards[r], m, argv + ai, nn_mode, postfilter, false);
     for (auto &t : th) t.join();
   }
   int rc = 0;

@@ -136,6 +136,7 @@ struct DevLayer { float *bias, *w, *rw, *wp, *rwp, *wq; };   // wq: narrow layer
 
 struct pn_ctx {
   int device, B, nn_mode;
+  int x3_rg;                       // split-precision mode: row groups of 32 per wave (1: 128-row blocks, 2: 256-row blocks), fixed at creation from B
   int small, small_gru;            // network kernel family per layer kind: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
   int fe_mode;                     // front end: FE_SPLIT = three phase kernels (pn_dsp_fe_split_*.hip); FE_MONO_G4 / FE_MONO_G2 = the
                                    // single-launch kernel with four / two streams per wavefront (pn_dsp_fe.hip, pn_dsp_fe_g2.hip)
@@ -257,7 +258,7 @@ static bool n16_rows_ok(int n_streams) {
 static int nn_selftest(pn_ctx *c);
 static int dsp_selftest(pn_ctx *c);
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru);
+                          int force_small, int force_small_gru, int force_x3_rg = 0);
 
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
@@ -282,7 +283,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
 // force_small / force_small_gru: -1 = choose the network kernel family from the batch size (the public behaviour);
 // 0 / 1 = the self-test's temporary contexts run the SAME family as the context under test whatever their own size.
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru) {
+                          int force_small, int force_small_gru, int force_x3_rg) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
   if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16 && nn_mode != PN_NN_MFMA_X3) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
@@ -295,7 +296,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   DeviceGuard _dg(device);
   if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_mode = pn_fe_mode_for(n_streams); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_mode = pn_fe_mode_for(n_streams); c->x3_rg = force_x3_rg ? force_x3_rg : pn_x3_rg_for(n_streams); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -415,9 +416,11 @@ extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0
 extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
-  const bool fam = c->nn_mode == PN_NN_MFMA;            // the small-batch family exists for the fp32 MFMA mode only
-  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, fam && c->small ? "small" : "batch",
-                         fam && c->small_gru ? "small" : "batch", fam && c->small ? "small" : "batch",
+  const bool x3 = c->nn_mode == PN_NN_MFMA_X3;
+  const bool fam = c->nn_mode == PN_NN_MFMA || x3;      // the small-batch family exists for the fp32 MFMA kernels only (in the split-precision mode: fc, fc_rb)
+  const char *xk = c->x3_rg == 2 ? "x3_rows64" : "x3_rows32";   // split-precision kernels: rows per wave (conv1, conv2, GRUs, fc_gb)
+  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
+                         x3 ? xk : (fam && c->small_gru ? "small" : "batch"), x3 ? xk : (fam && c->small ? "small" : "batch"),
                          c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
   return (w < 0 || (size_t)w >= n) ? -1 : w;
 }
@@ -512,13 +515,13 @@ static void launch_rnn(pn_ctx *c) {
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B, c->x3_rg);
     else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B, c->small); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B, c->x3_rg);
     else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 512, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B, c->small); }
   const float *x = c->c2out;
@@ -527,7 +530,7 @@ static void launch_rnn(pn_ctx *c) {
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B, c->x3_rg);
     else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
     else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
     x = hn;
@@ -539,14 +542,14 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B, c->x3_rg);
     else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
     else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B, c->x3_rg);
     else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
     else if (c->L[PN_L_FC_GB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
@@ -569,7 +572,7 @@ static void launch_rnn(pn_ctx *c) {
 // differs by more than 2e-5 (fp32 operands) / 4e-3 (fp16 operands, whose rounding the x3 weights amplify).  The verdict is cached for
 // the process; a self-test that cannot allocate its ~70 MB of temporaries is reported as SKIPPED, not as a failure.
 static std::mutex g_selftest_mu;
-static std::map<std::tuple<int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
+static std::map<std::tuple<int, int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
 
 static pn_model *selftest_model() {
   static std::vector<float> store;
@@ -600,7 +603,7 @@ static pn_model *selftest_model() {
 static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru);
+  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, c->nn_mode == PN_NN_MFMA_X3 ? c->x3_rg : 0);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
   const int rows = 192;
@@ -612,7 +615,7 @@ static int nn_selftest(pn_ctx *c) {
   bool oom = false;
   for (int pass = 0; pass < 2 && !rc; pass++) {          // pass 0: the kernel family under test; pass 1: STRICT kernels
     g_last_alloc_oom = false;
-    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru);
+    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru, c->x3_rg);
     if (!cx[pass]) { rc = -1; oom = g_last_alloc_oom; break; }
     unsigned x = 12345u;
     for (int step = 0; step < 2 && !rc; step++) {

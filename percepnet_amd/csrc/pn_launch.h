@@ -58,10 +58,11 @@ size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round);
 int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);   // -1: weight outside fp16 range
 int pn_dense_x3_nt(int N);
 void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows);
+                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg /* row groups of 32 per wave: 1 | 2 */);
 void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
-                      int n_rows);
+                      int n_rows, int rg);
+int pn_x3_rg_for(int n_rows);
 void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded);
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);

@@ -385,19 +385,22 @@ int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_rou
 
 int pn_dense_x3_nt(int N) { return N >= 128 ? 4 : 2; }
 
-// rows per wave: 2 row groups of 32 (256-row blocks, two per CU) or 1 (128-row blocks, three per CU)
-static int x3_rg() {
-  static const int rg = getenv("PERCEPNET_X3_RG") ? atoi(getenv("PERCEPNET_X3_RG")) : 2;
-  return rg == 1 ? 1 : 2;
+// rows per wave: 2 row groups of 32 (256-row blocks, two per CU: fewest operand bytes per MFMA, best when the grid fills
+// the chip several times over) or 1 (128-row blocks, three per CU: twice the blocks, shorter chains — measured 0.45 vs 0.60 ms
+// per frame at 1024 streams, 0.60 vs 0.68 at 4096, equal at 16 384, 0.60 vs 0.585 per GRU step at 65 536).  The context
+// fixes the choice at creation (and its self-test runs the same instantiation); PERCEPNET_X3_RG=1|2 overrides.
+int pn_x3_rg_for(int n_rows) {
+  static const int env = getenv("PERCEPNET_X3_RG") ? atoi(getenv("PERCEPNET_X3_RG")) : 0;
+  if (env == 1 || env == 2) return env;
+  return n_rows >= 32768 ? 2 : 1;
 }
 
 // A: panels carry the uint4* shadows of equally wide buffers (width = logical columns, a multiple of 32);
 // out (fp32, optional) / outS (shadow of a buffer nts_out column tiles wide, optional)
 void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows) {
+                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg) {
   const int tps = A.width[0] / 32, KT = tps * A.n;
   const int NT = pn_dense_x3_nt(N);
-  const int rg = x3_rg();
   const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg);
   const int n_cblocks = x3_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
@@ -412,9 +415,8 @@ void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const f
 
 void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
-                      int n_rows) {
+                      int n_rows, int rg) {
   const int tps = X.width[0] / 32, KTx = tps * X.n;
-  const int rg = x3_rg();
   const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg), NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
   if (rg == 2)

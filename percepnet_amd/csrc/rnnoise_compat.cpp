@@ -35,7 +35,13 @@ int rnnoise_get_size() { return (int)sizeof(DenoiseState); }
 // Still returns 0 (existing callers ignore the value and the reference cannot fail here), but an inert state is never
 // silent: one line on stderr says why no audio will come out.
 static int env_device() { const char *d = getenv("PERCEPNET_DEVICE"); return d ? atoi(d) : 0; }
-static int env_mode() { const char *s = getenv("PERCEPNET_STRICT"); return (s && atoi(s)) ? PN_NN_STRICT : PN_NN_MFMA; }
+// PERCEPNET_STRICT=1: reference-order network (bit-exact); PERCEPNET_X3=1: split-precision network; default fp32 MFMA
+static int env_mode() {
+  const char *s = getenv("PERCEPNET_STRICT");
+  if (s && atoi(s)) return PN_NN_STRICT;
+  const char *x = getenv("PERCEPNET_X3");
+  return (x && atoi(x)) ? PN_NN_MFMA_X3 : PN_NN_MFMA;
+}
 
 int rnnoise_init(DenoiseState *st, RNNModel *model) {
   memset(st, 0, sizeof(*st));

@@ -173,3 +173,52 @@ def test_x3_refuses_weights_outside_the_fp16_range():
         api.Context(m, 64, nn_mode=api.NN_MFMA_X3)
     c = api.Context(m, 64, nn_mode=api.NN_MFMA)              # the fp32 modes take the same model
     c.close(); m.close()
+
+
+def test_x3_through_the_cli_and_the_rnnoise_entry_points(blob, oracle, tmp_path):
+    """`percepnet_run --x3` (three ragged pairs) and the relinked reference main.cpp with PERCEPNET_X3=1 (one stream through
+    rnnoise_create / rnnoise_process_frame): the fp32 mode's bounds against the oracle."""
+    import os
+    import subprocess
+    from percepnet_amd import build
+    (tmp_path / "m.pnw").write_bytes(blob)
+    ins = [synth.synth_stream(40 + i, 15 + 4 * i) for i in range(3)]
+    args = []
+    for i, x in enumerate(ins):
+        (tmp_path / f"i{i}.pcm").write_bytes(x.tobytes()); args += [f"i{i}.pcm", f"o{i}.pcm"]
+    r = subprocess.run([build.RUN, "--model", "m.pnw", "--x3"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, x in enumerate(ins):
+        got = np.fromfile(tmp_path / f"o{i}.pcm", np.int16)
+        ref = oracle.run_pcm(x)[0]
+        assert got.size == ref.size and np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= PCM_TOL_LSB, i
+    exe = os.path.join(os.path.dirname(build.RUN), "percepNet_run_relinked")
+    if os.path.exists(exe):
+        env = dict(os.environ, PERCEPNET_MODEL=str(tmp_path / "m.pnw"), PERCEPNET_X3="1", PERCEPNET_SELFTEST="2")
+        r = subprocess.run([exe, "i0.pcm", "r0.pcm"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "nn_mode 3" in r.stderr, r.stderr                   # the self-test line names the mode the handle really runs
+        got = np.fromfile(tmp_path / "r0.pcm", np.int16)
+        ref = oracle.run_pcm(ins[0])[0]
+        assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= PCM_TOL_LSB
+        tap = np.fromfile(tmp_path / "feature_test.raw", np.float32).reshape(-1, 68)
+        assert np.abs(tap - oracle.run_pcm(ins[0])[1]).max() <= GR_TOL
+
+
+def test_x3_row_group_instantiations_agree_bit_for_bit(model):
+    """The split-precision kernels exist with 32 and with 64 rows per wave (chosen from the batch size at context creation:
+    64 from 32 768 streams).  Every output's MFMA sequence is the same in both, so the same stream must give the same bits
+    in a 300-stream context (32 rows per wave) and in a 32 768-stream one (64 rows per wave)."""
+    K, T = 300, 8
+    base = synth.synth_batch(16, T)
+    small = api.Context(model, K, nn_mode=api.NN_MFMA_X3)
+    big = api.Context(model, 32768, nn_mode=api.NN_MFMA_X3)
+    assert small.describe()["gru"] == "x3_rows32" and big.describe()["gru"] == "x3_rows64"
+    ps, pb = base[np.arange(K) % 16], base[np.arange(32768) % 16]
+    for t in range(T):
+        os_, gs = small.process_i16(ps[:, t * 480:(t + 1) * 480])
+        ob, gb = big.process_i16(pb[:, t * 480:(t + 1) * 480])
+        assert np.array_equal(gs.view(np.uint32), gb[:K].view(np.uint32)), t
+        assert np.array_equal(os_, ob[:K]), t
+        assert np.array_equal(gb[32768 - 16:].view(np.uint32), gb[:16].view(np.uint32)), t      # last block = first block (same streams)
+    small.close(); big.close()
