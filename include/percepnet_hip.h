@@ -132,7 +132,8 @@ int pn_ctx_compute_rnn_host(pn_ctx *ctx, const float *h_feat, float *h_gr);
    (nnet_data.h:28-38): conv1 [n_streams][4*128] and conv2 [n_streams][2*512] = the live part of the FIFOs, oldest
    frame first (nnet.cpp:191-199); gru1, gru2, gru3, gru_gb [n_streams][512]; gru_rb [n_streams][128].  NULL
    arrays are skipped.  Synchronous.  (Checkpoint/resume of the recurrent state, and what the exported
-   compute_rnn(RNNState*, ...) uses.) */
+   compute_rnn(RNNState*, ...) uses.)  Available in every network mode: the fp16-operand and split-precision modes keep
+   the fp32 values next to their operand shadows and re-derive the shadows on a load. */
 int pn_ctx_set_rnn_state_host(pn_ctx *ctx, const float *conv1, const float *conv2, const float *gru1, const float *gru2,
                               const float *gru3, const float *gru_gb, const float *gru_rb);
 int pn_ctx_get_rnn_state_host(pn_ctx *ctx, float *conv1, float *conv2, float *gru1, float *gru2, float *gru3,

@@ -894,15 +894,19 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
 static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2, float *const gru[4], float *rb) {
   PN_ON_DEVICE(c);
   if (pipe_drain(c)) return -1;
-  if (c->nn_mode == PN_NN_MFMA_F16) { pn_set_error("RNN state load/store is not available in the fp16-operand mode (shadow buffers)"); return -1; }
-  const bool x3 = c->nn_mode == PN_NN_MFMA_X3 && to_device;   // split-precision mode: the fp32 buffers are complete; a load re-derives the operand planes
+  // fp16-operand and split-precision modes: the fp32 buffers are complete (every layer stores fp32 next to its operand
+  // shadow), so a store reads them as in the fp32 modes and a load re-derives the shadows from the loaded fp32 values
+  const bool x3 = c->nn_mode == PN_NN_MFMA_X3 && to_device, f16 = c->nn_mode == PN_NN_MFMA_F16 && to_device;
   const size_t B = c->B, Bp = c->Bp; const int64_t t = c->tn;
   const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
   auto cp2d = [&](float *host, size_t hpitch, float *dev, size_t dpitch, size_t width) -> hipError_t {
     return to_device ? hipMemcpy2DAsync(dev, dpitch * 4, host, hpitch * 4, width * 4, B, kind, c->stream)
                      : hipMemcpy2DAsync(host, hpitch * 4, dev, dpitch * 4, width * 4, B, kind, c->stream);
   };
-  auto resplit = [&](float *dev, int width) { if (x3) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp); };
+  auto resplit = [&](float *dev, int width) {
+    if (x3) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp);
+    if (f16) pn_launch_shadow_f16(c->stream, dev, width, width, shadow(c, dev), (int)Bp);
+  };
   if (conv1) for (int j = 0; j < 4; j++) {
     float *d = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128;
     PN_HIP_CHECK(cp2d(conv1 + j * 128, 4 * 128, d, 128, 128)); resplit(d, 128);

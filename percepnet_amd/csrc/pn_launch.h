@@ -51,6 +51,7 @@ void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, int a_half, const void
 void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float *h_old, const void *h_oldH,
                        const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
                        float *h_new, void *h_newH, int n_rows);
+void pn_launch_shadow_f16(hipStream_t st, const float *src, int ld, int width, void *dstH, int n_rows_padded);
 int pn_dense_nt(int N);
 // split-precision variant (pn_nn_x3.hip): operands as fp16 hi/lo planes in fragment order; panels of A / h_oldS / outS /
 // h_newS are the uint4* shadows (carried as float* in PnSegs), width = logical columns (multiple of 32)

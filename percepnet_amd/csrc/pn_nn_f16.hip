@@ -308,6 +308,28 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_f16_kernel(
   }
 }
 
+// ---- fp32 rows -> tile-major fp16 shadow [M tile][column tile][128][32] (an RNN state loaded from the host) ---------
+// one thread per (row, 8 columns): reads 32 bytes, writes 16
+__global__ __launch_bounds__(256) void pn_shadow_f16_kernel(const float *__restrict__ src, int ld, int width,
+                                                            _Float16 *__restrict__ dst, int n_rows_padded) {
+  const int groups = width >> 3;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = idx / groups;
+  const int c8 = (int)(idx - row * groups) * 8;
+  if (row >= (size_t)n_rows_padded) return;
+  const float4 a = *reinterpret_cast<const float4 *>(src + row * ld + c8), b = *reinterpret_cast<const float4 *>(src + row * ld + c8 + 4);
+  half8 h;
+  h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+  h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+  _Float16 *tile = dst + ((row / BM) * (width >> 5) + (c8 >> 5)) * (size_t)(BM * 32);
+  *reinterpret_cast<half8 *>(tile + (row % BM) * 32 + (c8 & 31)) = h;
+}
+void pn_launch_shadow_f16(hipStream_t st, const float *src, int ld, int width, void *dst, int n_rows_padded) {
+  const size_t n = (size_t)n_rows_padded * (width >> 3);
+  hipLaunchKernelGGL(pn_shadow_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ld, width, (_Float16 *)dst,
+                     n_rows_padded);
+}
+
 // ---- host: fp16 weight packing: W[K][ncols] -> [CT][ceil(K/64)][32 cols][64 k] halfs, zero padded ----
 static inline int h_ct_padded(int ncols, int ct_round) {
   const int CT = (ncols + 31) / 32;

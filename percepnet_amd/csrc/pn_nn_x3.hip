@@ -62,8 +62,10 @@ template <int RG>
 __device__ __forceinline__ void x3_load_A(X3A<RG> &q, const uint4 *__restrict__ pt, int s) {
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) q.h[rg] = *reinterpret_cast<const fvec4 *>(pt + s * 256 + 32 * rg);
+#ifndef X3_TIMING_NP1
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) q.l[rg] = *reinterpret_cast<const fvec4 *>(pt + X3_PLANE + s * 256 + 32 * rg);
+#endif
 }
 
 // one 32-k tile (two k-steps): acc[rg][IDX[t]] += A * B[t] for both row groups, three products each (small terms
@@ -73,16 +75,24 @@ struct X3B { fvec4 h, l; };
 __device__ __forceinline__ X3B x3_read_B(const uint4 (*Bs)[4][64], int t, int s, int lane) {
   X3B f;
   f.h = *reinterpret_cast<const fvec4 *>(&Bs[t][2 * s][lane]);
+#ifndef X3_TIMING_NP1
   f.l = *reinterpret_cast<const fvec4 *>(&Bs[t][2 * s + 1][lane]);
+#else
+  f.l = f.h;
+#endif
   return f;
 }
 template <int RG>
 __device__ __forceinline__ void x3_mma6(const X3A<RG> &q, const X3B &f, floatx16 (&acc)[RG][4], int idx) {
   const half8 bh = x3_h8(f.h), bl = x3_h8(f.l);
+#ifndef X3_TIMING_NP1      // (timing experiment: what a hi-plane-only kernel of this shape would cost; results are wrong)
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.l[rg]), bh, acc[rg][idx], 0, 0, 0);
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bl, acc[rg][idx], 0, 0, 0);
+#else
+  (void)bl;
+#endif
 #pragma unroll
   for (int rg = 0; rg < RG; rg++) acc[rg][idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_h8(q.h[rg]), bh, acc[rg][idx], 0, 0, 0);
 }

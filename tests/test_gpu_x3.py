@@ -142,17 +142,19 @@ def test_x3_mode_on_other_weight_sets(name):
     assert dg.max() <= tol, float(dg.max())
 
 
-def test_x3_rnn_state_roundtrip(model, oracle):
-    """get/set of the RNNState arrays (nnet_data.h:28-38) in the split-precision mode: loading a state re-derives the
-    operand planes, so a context restored from another's state continues bit-identically to it."""
+@pytest.mark.parametrize("mode", [api.NN_MFMA_X3, api.NN_MFMA_F16], ids=["x3", "f16"])
+def test_x3_rnn_state_roundtrip(model, oracle, mode):
+    """get/set of the RNNState arrays (nnet_data.h:28-38) in the modes that keep operand shadows (split precision: hi/lo
+    planes; fp16 operands: fp16 copies): loading a state re-derives the shadows from the fp32 values, so a context
+    restored from another's state continues bit-identically to it."""
     B, T = 130, 6
     rng = np.random.default_rng(3)
     feats = rng.standard_normal((T, B, 70)).astype(np.float32)
-    a = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    a = api.Context(model, B, nn_mode=mode)
     for t in range(3):
         a.compute_rnn(feats[t])
     st = a.get_rnn_state()
-    b = api.Context(model, B, nn_mode=api.NN_MFMA_X3)
+    b = api.Context(model, B, nn_mode=mode)
     for t in range(3):
         b.compute_rnn(feats[5 - t])                          # a different history, then overwritten
     # the ring phase (which slot is "oldest") is part of the context, not of the state: bring b to the same frame count
