@@ -219,13 +219,14 @@ def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
     avg_s = ms / n * 1e-3
     flops = B * GRU512_FLOP_PER_STREAM_FRAME
     x3 = desc.get("nn") == "mfma_x3"
-    kname = "pn_gru_x3_kernel" if x3 else ("pn_gru_f16_kernel" if fp16 else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel"))
+    # the fp16-operand mode runs the hi-plane-only instantiation of the split-precision kernels (pn_nn_x3.hip)
+    kname = "pn_gru_x3_kernel" if (x3 or fp16) else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel")
     traffic, traffic_src = pmc_traffic_bytes(B, kname[:11], traffic_tag)
     ach = flops / avg_s / 1e12
     # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md).  Split precision: `achieved` stays the ALGORITHMIC rate (2 M N K per
     # launch); every product costs three fp16 MFMAs, so the bound is a third of the dense fp16 peak
     peak = round(2500.0 / 3, 1) if x3 else (2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS)
-    r = {"kernel": kname + " (512->512 reset-after GRU step, 4 launches per frame)",
+    r = {"kernel": kname + ("<rows/32, planes=1>" if fp16 else ("<rows/32, planes=2>" if x3 else "")) + " (512->512 reset-after GRU step, 4 launches per frame)",
          "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": traffic,
          "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),

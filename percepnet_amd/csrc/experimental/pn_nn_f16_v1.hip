@@ -1,3 +1,5 @@
+// NOT BUILT (round 3): the first-generation fp16-operand kernels, replaced by the hi-plane-only instantiation of
+// pn_nn_x3.hip (A fragments straight from a fragment-order shadow, 64-row wave tiles).  Kept for the measurements DESIGN.md 4.2b cites.
 // fp16-input variant of the gain-network kernels (BASELINE.json configs[4]: "fp16 weights/activations
 // variant, tolerance re-stated vs CPU fp32 reference") for gfx950.
 //
@@ -15,7 +17,7 @@
 //
 // Tile: 128 streams x (NT x 32) columns per 256-thread block, K-tile 64 (four MFMA k-steps of 16);
 // LDS rows padded to 72 halfs (144 B) -> conflict-free ds_read_b128 / ds_write_b64.
-#include "pn_nn_common.h"
+#include "../pn_nn_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

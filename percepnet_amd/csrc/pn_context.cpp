@@ -356,26 +356,16 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
       const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
       const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
       const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
-      if (nn_mode == PN_NN_MFMA_X3 && x3_layer(li)) {      // conv1, conv2, the GRUs and fc_gb; fc and fc_rb (K = 70 / 128) stay fp32 below
+      if ((nn_mode == PN_NN_MFMA_X3 || nn_mode == PN_NN_MFMA_F16) && x3_layer(li)) {   // conv1, conv2, the GRUs and fc_gb; fc and fc_rb (K = 70 / 128) stay fp32 below
+        const int np = nn_mode == PN_NN_MFMA_X3 ? 2 : 1;         // operand planes: hi + lo (split precision) or hi only (fp16 operands)
         const int ctx3 = H.kind == PN_KIND_GRU ? 1 : pn_dense_x3_nt(H.nn);
-        std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3));
-        if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the split-precision mode cannot represent it", li); goto fail; }
+        std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3, np));
+        if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, np, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the fp16-operand and split-precision modes cannot represent it", li); goto fail; }
         if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
         if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
         if (nr) {
-          std::vector<uint16_t> rp(pn_packed_halfs_x3(H.nn, ncols, 1));
-          if (pn_pack_weights_x3(H.rw, H.nn, H.nn, ncols, 1, rp.data())) { pn_set_error("layer %d has a recurrent weight outside the fp16 range", li); goto fail; }
-          if (upload(c, &c->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail;
-          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
-        }
-      } else if (nn_mode == PN_NN_MFMA_F16) {
-        std::vector<uint16_t> packed(pn_packed_halfs(k_alloc, ncols, ctr));
-        pn_pack_weights_f16(H.w, K, k_alloc, ncols, ctr, packed.data());
-        if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
-        if (nr) {
-          std::vector<uint16_t> rp(pn_packed_halfs(H.nn, ncols, 1));
-          pn_pack_weights_f16(H.rw, H.nn, H.nn, ncols, 1, rp.data());
+          std::vector<uint16_t> rp(pn_packed_halfs_x3(H.nn, ncols, 1, np));
+          if (pn_pack_weights_x3(H.rw, H.nn, H.nn, ncols, 1, np, rp.data())) { pn_set_error("layer %d has a recurrent weight outside the fp16 range", li); goto fail; }
           if (upload(c, &c->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail;
           if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
         }
@@ -416,9 +406,10 @@ extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0
 extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
-  const bool x3 = c->nn_mode == PN_NN_MFMA_X3;
-  const bool fam = c->nn_mode == PN_NN_MFMA || x3;      // the small-batch family exists for the fp32 MFMA kernels only (in the split-precision mode: fc, fc_rb)
-  const char *xk = c->x3_rg == 2 ? "x3_rows64" : "x3_rows32";   // split-precision kernels: rows per wave (conv1, conv2, GRUs, fc_gb)
+  const bool x3 = c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16;      // shadow-operand kernels (pn_nn_x3.hip)
+  const bool fam = c->nn_mode == PN_NN_MFMA || x3;      // the small-batch family exists for the fp32 MFMA kernels only (in the shadow-operand modes: fc, fc_rb)
+  const char *xk = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 2 ? "x3_rows64" : "x3_rows32")      // rows per wave (conv1, conv2, GRUs, fc_gb)
+                                               : (c->x3_rg == 2 ? "f16_rows64" : "f16_rows32");
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
                          x3 ? xk : (fam && c->small_gru ? "small" : "batch"), x3 ? xk : (fam && c->small ? "small" : "batch"),
                          c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
@@ -502,27 +493,26 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
 
 static void launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
-  const bool f16 = c->nn_mode == PN_NN_MFMA_F16, x3 = c->nn_mode == PN_NN_MFMA_X3;
+  // x3: the layers that run on the fp16 matrix cores from operand shadows — split precision (hi + lo planes) or fp16 operands (hi only)
+  const bool x3 = c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16;
+  const int np = c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1;
   hipStream_t st = c->stream; const float *tab = c->tansig;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
   float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128;
   float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512;
   { Scope sc(c, KF_FC);
     PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
-    if (f16) pn_launch_dense_f16(st, A, 0, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, shadow(c, c1new), 128, (int)B);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
-    if (x3) pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp); }   // fc runs in fp32 (70 inputs); its output enters the split-precision layers
+    pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
+    if (x3) pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp, np); }   // fc runs in fp32 (70 inputs); its output enters the shadow-operand layers
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B, c->x3_rg);
-    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 512, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B, c->x3_rg, np);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B, c->small); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B, c->x3_rg);
-    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 512, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B, c->x3_rg, np);
     else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B, c->small); }
   const float *x = c->c2out;
   for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
@@ -530,8 +520,7 @@ static void launch_rnn(pn_ctx *c) {
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B, c->x3_rg);
-    else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B, c->x3_rg, np);
     else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
     x = hn;
   }
@@ -542,21 +531,18 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B, c->x3_rg);
-    else if (f16) pn_launch_gru_f16(st, shadow_segs(c, X), 1, rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B);
+    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B, c->x3_rg, np);
     else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B, c->x3_rg);
-    else if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B);
+    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B, c->x3_rg, np);
     else if (c->L[PN_L_FC_GB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
   { Scope sc(c, KF_FC_RB);
     PnSegs A = seg1(rbn, 128, 128);
-    if (f16) pn_launch_dense_f16(st, shadow_segs(c, A), 1, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, NULL, 0, (int)B);
-    else if (c->L[PN_L_FC_RB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
+    if (c->L[PN_L_FC_RB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
     else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B, c->small); }
 }
 
@@ -603,7 +589,7 @@ static pn_model *selftest_model() {
 static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, c->nn_mode == PN_NN_MFMA_X3 ? c->x3_rg : 0);
+  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : 0);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
   const int rows = 192;
@@ -904,8 +890,8 @@ static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2,
                      : hipMemcpy2DAsync(host, hpitch * 4, dev, dpitch * 4, width * 4, B, kind, c->stream);
   };
   auto resplit = [&](float *dev, int width) {
-    if (x3) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp);
-    if (f16) pn_launch_shadow_f16(c->stream, dev, width, width, shadow(c, dev), (int)Bp);
+    if (x3) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 2);
+    if (f16) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 1);
   };
   if (conv1) for (int j = 0; j < 4; j++) {
     float *d = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128;

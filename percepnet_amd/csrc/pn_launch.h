@@ -42,29 +42,19 @@ void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const f
                        void *out, int out_is_i16);
 size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
 void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
-size_t pn_packed_halfs(int k_alloc, int ncols, int ct_round);
-void pn_pack_weights_f16(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);
-// fp16-operand variant: a_half = the A panels are fp16 shadow buffers (pointers carried as float*, ld in halfs);
-// outH / h_newH: fp16 shadow of the output (same indexing as the fp32 one), may be NULL
-void pn_launch_dense_f16(hipStream_t st, const PnSegs &A, int a_half, const void *Wp, const float *bias, int N, int act,
-                         const float *tansig, float *out, int ldo, void *outH, int ldoH, int n_rows);
-void pn_launch_gru_f16(hipStream_t st, const PnSegs &X, int a_half, const float *h_old, const void *h_oldH,
-                       const void *Wp, const void *Up, const float *b, int N, int act, const float *tansig,
-                       float *h_new, void *h_newH, int n_rows);
-void pn_launch_shadow_f16(hipStream_t st, const float *src, int ld, int width, void *dstH, int n_rows_padded);
 int pn_dense_nt(int N);
 // split-precision variant (pn_nn_x3.hip): operands as fp16 hi/lo planes in fragment order; panels of A / h_oldS / outS /
 // h_newS are the uint4* shadows (carried as float* in PnSegs), width = logical columns (multiple of 32)
-size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round);
-int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, void *Wp);   // -1: weight outside fp16 range
+size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round, int np /* planes: 2 = hi+lo (split precision), 1 = fp16 operands */);
+int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, int np, void *Wp);   // -1: weight outside fp16 range
 int pn_dense_x3_nt(int N);
 void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
-                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg /* row groups of 32 per wave: 1 | 2 */);
+                        const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg /* row groups of 32 per wave: 1 | 2 */, int np);
 void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
-                      int n_rows, int rg);
+                      int n_rows, int rg, int np);
 int pn_x3_rg_for(int n_rows);
-void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded);
+void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np);
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);

@@ -1,4 +1,4 @@
-// Shared device helpers of the network kernels (pn_nn.hip: fp32 MFMA + STRICT, pn_nn_f16.hip: fp16-input MFMA).
+// Shared device helpers of the network kernels (pn_nn.hip: fp32 MFMA + STRICT, pn_nn_small.hip, pn_nn_x3.hip: fp16 matrix cores).
 #pragma once
 #include "pn_common.h"
 
@@ -127,7 +127,7 @@ __device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float
     const int row = row0 + (i & 3) + 8 * (i >> 2);
     if (row < n_rows) {
       h_new[(size_t)row * N + col] = v[i];
-      // fp16 shadow for the fp16-operand variant, tile-major [M tile][column tile][128][32] (pn_nn_f16.hip)
+      // fp16 shadow in the first-generation fp16 kernels' layout, tile-major [M tile][column tile][128][32] (experimental/pn_nn_f16_v1.hip)
       if (h_newH) h_newH[(((size_t)(row / BM) * (N >> 5) + (col >> 5)) * BM + (row % BM)) * 32 + (col & 31)] = (_Float16)v[i];
     }
   }
