@@ -171,7 +171,9 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_dense_x3_kernel(
   int mt, cb;
   if (!pn_tile_of_block(n_mtiles, n_cblocks, mt, cb)) return;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
+  // the activation table (201 entries): one value per thread, loaded together with the first operand tiles and written to
+  // LDS before the first barrier — staged up front it cost a full memory latency before any operand load was issued
+  const float ts_v = tansig[tid < 201 ? tid : 200];
   floatx16 acc[RG][4];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_dense_x3_kernel(
   { XD_APTR(0, p0); x3_load_A<RG, NP>(q0, p0, 0); x3_load_A<RG, NP>(q1, p0, 1); }
   { XD_APTR(1, p1); x3_load_A<RG, NP>(q2, p1, 0); x3_load_A<RG, NP>(q3, p1, 1); }
   XD_BLOAD(0); XD_BSTASH(0); XD_BLOAD(1);
+  if (tid < 201) S.tansig[tid] = ts_v;
   __syncthreads();
 #pragma unroll 1
   for (int g = 0; g < KT; g += 2) {
@@ -263,7 +266,9 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_x3_kernel(
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int KTh = NTn, T1 = KTx, TT = KTx + KTh;
   const int col = nt * 32 + (lane & 31);
-  for (int i = tid; i < 201; i += (int)blockDim.x) S.tansig[i] = tansig[i];
+  // the activation table (201 entries): one value per thread, loaded together with the first operand tiles and written to
+  // LDS before the first barrier — staged up front it cost a full memory latency before any operand load was issued
+  const float ts_v = tansig[tid < 201 ? tid : 200];
   floatx16 acc[RG][4];
   {
     float bz = b[col]; bz += b[3 * N + col];
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_x3_kernel(
   { XG_APTR(0, p0); x3_load_A<RG, NP>(q0, p0, 0); x3_load_A<RG, NP>(q1, p0, 1); }
   { XG_APTR(1, p1); x3_load_A<RG, NP>(q2, p1, 0); x3_load_A<RG, NP>(q3, p1, 1); }
   XG_BLOAD(0); XG_BSTASH(0); XG_BLOAD(1);
+  if (tid < 201) S.tansig[tid] = ts_v;
   __syncthreads();
   X3_STAMP(1);
 #pragma unroll 1
@@ -329,13 +335,18 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_x3_kernel(
     const float bh = b[2 * N + col];
     float *T = reinterpret_cast<float *>(&S.B[0][0][0][0]) + wave * 32 * X3_TLD;
     uint4 *Sx = h_newS ? h_newS + ((size_t)mt128 * NTn + nt) * (NP * X3_PLANE) : nullptr;
+    // previous state for the blend: the loads of all row groups in flight before any activation arithmetic
+    float ho[RG][16];
+#pragma unroll
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        ho[rg][i] = h_old[(size_t)(mt * XMB + 32 * RG * wave + 32 * rg + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
 #pragma unroll
     for (int rg = 0; rg < RG; rg++) {
       const int grow0 = mt * XMB + 32 * RG * wave + 32 * rg;
-      float ho[16], v[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) ho[i] = h_old[(size_t)(grow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-      pn_gru_gate16(acc[rg][0], acc[rg][1], acc[rg][2], acc[rg][3], ho, bh, act, S.tansig, v);
+      float v[16];
+      pn_gru_gate16(acc[rg][0], acc[rg][1], acc[rg][2], acc[rg][3], ho[rg], bh, act, S.tansig, v);
       x3_store_tile<NP>(T, v, h_new, N, nt * 32, N, grow0, n_rows, Sx, srow + 32 * rg, lane);
     }
   }
