@@ -9,7 +9,8 @@ if [ "$MODE" = "tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/pytest_$TAG.log 2>&1; echo "pytest rc=$?" >> $O/pytest_$TAG.log
   tail -5 $O/pytest_$TAG.log
 fi
-timeout 600 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err; tail -c 600 $O/bench_$TAG.err
+T0=$(date +%s); timeout 600 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "default bench.py wall seconds: $(( $(date +%s) - T0 ))" | tee $O/bench_${TAG}_wall.txt; tail -c 600 $O/bench_$TAG.err
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke_$TAG.txt
 timeout 300 python bench.py --streams 1024 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_${TAG}_1024.json 2>> $O/bench_$TAG.err
 timeout 300 python bench.py --fp16 --no-cpu-baseline > $O/bench_${TAG}_fp16.json 2>> $O/bench_$TAG.err
 timeout 300 python bench.py --x3 --no-cpu-baseline > $O/bench_${TAG}_x3.json 2>> $O/bench_$TAG.err
