@@ -1,5 +1,7 @@
-// Split-precision network kernels for gfx950 (nn_mode PN_NN_MFMA_X3): fp32 GEMMs of the gain network evaluated on
-// the fp16 matrix cores with error compensation, fp32 accumulation and fp32 state.
+// Shadow-operand network kernels for gfx950: the GEMMs of the gain network on the fp16 matrix cores, operands taken
+// from fragment-order fp16 shadows of the activations, fp32 accumulation and fp32 state.  Two instantiations:
+//   NP = 2  split precision (nn_mode PN_NN_MFMA_X3): fp32 GEMMs with error compensation, described below;
+//   NP = 1  fp16 operands (nn_mode PN_NN_MFMA_F16, BASELINE configs[4]): the hi plane only, one MFMA per operand pair.
 //
 // Every GEMM operand x (activation or weight, fp32) is carried as two fp16 numbers, hi = fp16(x) and
 // lo = fp16(x - hi) (x - hi is exact in fp32; v_mfma_f32_32x32x16_f16 honours fp16 subnormals on gfx950 —
@@ -7,13 +9,15 @@
 // precision of 2^-22 above), and every product a*b is formed as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  by three MFMAs into
 // the same fp32 accumulator; the dropped a_lo*b_lo term is below 2^-22 |a b|.  The operand error of a length-1024 dot
 // product is then ~5x SMALLER than the rounding error the reference's own sequential fp32 accumulation makes
-// (tools/x3_error_model.py), so the deviation of this mode from the CPU path is, like PN_NN_MFMA's, the summation
+// (measured against float64 arithmetic: tools/x3_vs_f64.py — max |g,r - exact| 2.0e-6 for this mode, 2.6e-6 for the CPU
+// reference itself), so the deviation of this mode from the CPU path is, like PN_NN_MFMA's, the summation
 // order — measured against the same bounds (+-1 LSB PCM, 2e-5 on g/r; tests/test_gpu_x3.py).  The fp16 matrix
 // cores run 16x the fp32 MFMA rate: three products still leave 5.3x, which moves these GEMMs from MFMA-bound to
 // LDS/L2-bound.  Bias preload, table tanh/sigmoid, gating, the state blend and every stored state value stay fp32.
 //
 // Tiling (different from pn_nn.hip because the limiter is different):
-//   block = 4 waves x 64 rows = 256 streams, NT column tiles of 32 (the three gate tiles of one n-tile for a GRU);
+//   block = 4 waves x 64 rows = 256 streams (RG = 2; RG = 1: 32 rows per wave, 128-row blocks, for batches below 32 768
+//   streams), NT column tiles of 32 (the three gate tiles of one n-tile for a GRU);
 //   A (activations) is NOT staged through LDS: a wave's rows are private to it, so its MFMA fragments are loaded
 //   straight from global memory into registers from a FRAGMENT-ORDER shadow of the producing layer's output,
 //     shadow[M tile of 128][column tile of 32][plane hi|lo][k-group of 8][row 0..127][8 halfs]        (8 KB per plane)
