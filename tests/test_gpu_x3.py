@@ -244,3 +244,29 @@ def test_split_precision_is_as_close_to_exact_arithmetic_as_the_cpu_reference(na
     assert x3["max"] <= 2.0 * cpu["max"] and x3["rms"] <= 2.5 * cpu["rms"], (x3, cpu)
     assert mf["max"] <= 2.0 * cpu["max"] and mf["rms"] <= 1.5 * cpu["rms"], (mf, cpu)
     assert f16["rms"] >= 10 * x3["rms"], (f16, x3)
+
+
+@pytest.mark.parametrize("mode", [api.NN_MFMA_X3, api.NN_MFMA_F16], ids=["x3", "f16"])
+def test_shadow_operand_kernels_ragged_last_block_at_64_rows_per_wave(model, mode):
+    """32 768 + 129 streams: the 64-rows-per-wave instantiation (256-row blocks) with a ragged last block whose second
+    128-row operand chunk holds a single stream.  Every replica of a stream must be bit-identical wherever it sits — the
+    last, ragged block included — and equal to the same stream in a small context (32 rows per wave)."""
+    B, K, T = 32768 + 129, 16, 6
+    base = synth.synth_batch(K, T)
+    big = api.Context(model, B, nn_mode=mode)
+    small = api.Context(model, K, nn_mode=mode)
+    assert big.describe()["gru"].endswith("rows64") and small.describe()["gru"].endswith("rows32")
+    idx = np.arange(B) % K
+    pb = base[idx]
+    for t in range(T):
+        ob, gb = big.process_i16(pb[:, t * 480:(t + 1) * 480])
+        os_, gs = small.process_i16(base[:, t * 480:(t + 1) * 480])
+        assert np.isfinite(gb).all()
+        for k in range(K):
+            m = idx == k
+            g = gb[m].view(np.uint32)
+            assert (g == g[0]).all(), (t, k, "g/r replicas")
+            assert (ob[m] == ob[m][0]).all(), (t, k, "pcm replicas")
+        assert np.array_equal(gb[:K].view(np.uint32), gs.view(np.uint32)), t
+        assert np.array_equal(ob[:K], os_), t
+    big.close(); small.close()
