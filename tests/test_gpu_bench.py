@@ -37,6 +37,22 @@ def test_single_rank_line_has_measured_parity_and_roofline():
     assert abs(r["value"] * 100 - r["frames_per_s"]) < 10
 
 
+def test_split_precision_and_fp16_lines():
+    """`--x3` and `--fp16`: the line names the mode, the dtype string says what is computed, the parity numbers are the
+    run's own and inside the mode's bound, and the roofline is priced against the fp16 matrix peak (a third of it for the
+    three-product mode)."""
+    r = _bench("--x3", "--streams", "2048", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-sustained")
+    assert r["config"]["nn_mode"] == "mfma_x3" and "hi+lo" in r["dtype"]
+    assert r["config"]["kernel_families"]["gru"] == "x3_rows32"
+    assert r["max_abs_delta_vs_cpu_ref_lsb"] <= 1 and r["max_abs_delta_gr"] <= 2e-5
+    assert abs(r["roofline"]["peak"] - 2500.0 / 3) < 0.1 and r["roofline"]["kernel"].startswith("pn_gru_x3_kernel")
+    r = _bench("--fp16", "--streams", "2048", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-sustained")
+    assert r["config"]["nn_mode"] == "mfma_f16" and r["dtype"].startswith("f16")
+    assert r["config"]["kernel_families"]["gru"] == "f16_rows32"
+    assert r["max_abs_delta_vs_cpu_ref_lsb"] <= 6 and r["max_abs_delta_gr"] <= 1e-3
+    assert r["roofline"]["peak"] == 2500.0
+
+
 def test_two_ranks_self_launched():
     r = _bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "1024", "--steps", "5", "--warmup", "2")
     assert r["n_gpus"] == 2 and [x["rank"] for x in r["ranks"]] == [0, 1]
