@@ -270,3 +270,33 @@ def test_shadow_operand_kernels_ragged_last_block_at_64_rows_per_wave(model, mod
         assert np.array_equal(gb[:K].view(np.uint32), gs.view(np.uint32)), t
         assert np.array_equal(ob[:K], os_), t
     big.close(); small.close()
+
+
+def test_x3_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle):
+    """The benchmarked configuration of the split-precision mode (65 536 concurrent streams: 64 rows per wave, 256-row
+    blocks, 16 blocks per CU and launch) over the 10 s horizon: 256 distinct sampled streams scattered through the batch
+    against the oracle, the other slots carrying rotated replicas as in bench.py — same layout and bounds as
+    test_gpu_longrun.py::test_configs2_65536_streams_1000_frames_256_sampled_vs_oracle."""
+    import torch
+    from test_gpu_longrun import sample_layout
+    B, T, P = 65536, 1000, 256
+    dev = torch.device("cuda:0")
+    pool = synth.synth_batch_parallel(P, T)
+    ref = oracle.run_batch(pool, group=8)
+    slots, idx, rot = sample_layout(B, P)
+    ts = shared_stream(dev)
+    with torch.cuda.stream(ts):
+        d_pool = torch.from_numpy(pool).to(dev)
+        d_idx = torch.from_numpy(idx).to(dev)
+        ar = (torch.arange(480, device=dev)[None, :] + torch.from_numpy(rot).to(dev)[:, None]) % 480
+        rows = torch.from_numpy(slots).to(dev)
+
+        def frame_of(t):
+            return torch.gather(d_pool[:, t * 480:(t + 1) * 480][d_idx], 1, ar).contiguous()
+
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3, stream=ts.cuda_stream)
+        assert ctx.describe()["gru"] == "x3_rows64"
+        got = run_long(ctx, frame_of, T, rows, dev)
+        ctx.close()
+    compare("x3_65536x1000_sample256", got, ref, {
+        "config": "split-precision network mode, 65536 concurrent streams, 256 distinct sampled streams vs the CPU oracle"})
