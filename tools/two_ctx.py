@@ -8,7 +8,8 @@ B = int(sys.argv[1]); NC = int(sys.argv[2]); K = int(sys.argv[3]) if len(sys.arg
 dev = torch.device("cuda:0")
 model = api.Model(weights.default_blob(1234))
 streams = [torch.cuda.Stream() for _ in range(NC)]
-ctxs = [api.Context(model, B, stream=s.cuda_stream) for s in streams]
+MODE = {'f32': api.NN_MFMA, 'f16': api.NN_MFMA_F16, 'x3': api.NN_MFMA_X3}[os.environ.get('PN_MODE', 'f32')]
+ctxs = [api.Context(model, B, nn_mode=MODE, stream=s.cuda_stream) for s in streams]
 P = 64; T = K + 2
 pool = torch.from_numpy(synth.synth_batch(P, T)).to(dev)
 idx = torch.arange(B, device=dev) % P
@@ -25,4 +26,4 @@ if SKEW and NC > 1:
     with torch.cuda.stream(streams[1]):
         torch.cuda._sleep(SKEW)
 t0 = time.perf_counter(); run(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"lib={os.environ.get('PERCEPNET_LIB','default').split('/')[-2] if os.environ.get('PERCEPNET_LIB') else 'default'} skew={SKEW} ctx={NC} x {B}: {1e3*dt/K:.3f} ms/step-pair -> {NC*B*K/dt/100:.0f} streams")
+print(f"mode={os.environ.get('PN_MODE','f32')} lib={os.environ.get('PERCEPNET_LIB','default').split('/')[-2] if os.environ.get('PERCEPNET_LIB') else 'default'} skew={SKEW} ctx={NC} x {B}: {1e3*dt/K:.3f} ms/step-pair -> {NC*B*K/dt/100:.0f} streams")
