@@ -300,3 +300,21 @@ def test_x3_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle):
         ctx.close()
     compare("x3_65536x1000_sample256", got, ref, {
         "config": "split-precision network mode, 65536 concurrent streams, 256 distinct sampled streams vs the CPU oracle"})
+
+
+def test_shadow_operand_kernels_never_read_past_their_buffers():
+    """PERCEPNET_GUARD=1 puts 1 MB of 0xFF (NaN as fp32 and fp16) behind every device buffer: an operand fetched past the
+    end of a shadow, a packed weight array or a state buffer (clamped prefetch tiles, ragged last blocks, padding rows)
+    would surface as a NaN or a large error.  33 025 streams = the 64-rows-per-wave kernels with a ragged last block."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PERCEPNET_GUARD="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_check.py"), "33025", "4"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"x3 vs strict: max\|dPCM\| (\d+) LSB .* max\|dg,r\| ([0-9.e+-]+), .* finite (\w+)", r.stdout)
+    assert m, r.stdout[-1000:]
+    assert int(m.group(1)) <= PCM_TOL_LSB and float(m.group(2)) <= GR_TOL and m.group(3) == "True", m.group(0)
