@@ -95,4 +95,7 @@ def test_bench_launches_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0
-    assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
+    # the elastic agent SIGTERMs the surviving rank as soon as the first one exits, so one or two ranks get to print the
+    # message; the agent's failure report names every rank it launched
+    assert 1 <= out.stderr.count("bench.py needs a GPU") <= 2, out.stderr[-2000:]
+    assert "local_rank: 0" in out.stderr and "local_rank: 1" in out.stderr, out.stderr[-2000:]
