@@ -408,10 +408,11 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
   const bool x3 = c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16;      // shadow-operand kernels (pn_nn_x3.hip)
   const bool fam = c->nn_mode == PN_NN_MFMA || x3;      // the small-batch family exists for the fp32 MFMA kernels only (in the shadow-operand modes: fc, fc_rb)
-  const char *xk = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 2 ? "x3_rows64" : "x3_rows32")      // rows per wave (conv1, conv2, GRUs, fc_gb)
-                                               : (c->x3_rg == 2 ? "f16_rows64" : "f16_rows32");
+  // rows per wave (conv1, conv2, GRUs, fc_gb); x3_rg 3 = 64 rows with the GRUs on the paired-phase kernel (pn_gru_x3p_kernel)
+  const char *xk = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg >= 2 ? "x3_rows64" : "x3_rows32") : (c->x3_rg >= 2 ? "f16_rows64" : "f16_rows32");
+  const char *xg = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 3 ? "x3_rows64_paired" : xk) : (c->x3_rg == 3 ? "f16_rows64_paired" : xk);
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
-                         x3 ? xk : (fam && c->small_gru ? "small" : "batch"), x3 ? xk : (fam && c->small ? "small" : "batch"),
+                         x3 ? xg : (fam && c->small_gru ? "small" : "batch"), x3 ? xg : (fam && c->small ? "small" : "batch"),
                          c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
   return (w < 0 || (size_t)w >= n) ? -1 : w;
 }
