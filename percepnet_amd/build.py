@@ -26,6 +26,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+# per-source extra flags.  pn_nn_x3.hip: no SLP vectorisation — packed f32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32)
+# issued beside a wave that keeps the SIMD's matrix pipe busy are 4x slower than beside an idle one (DESIGN.md 4.2f,
+# tools/probes/mfma_valu_pair_probe.hip), and the gating epilogues of these kernels run exactly there
+# -pragma-unroll-threshold: the paired-phase GRU kernel's epilogue phase is ONE fully unrolled loop over its 32 / 36 barrier steps
+# (every step then has compile-time register sets, ring slots and tile numbers); the default limit of `#pragma unroll` (16 K
+# IR instructions, counted before the per-step branches fold) silently leaves it rolled — with every array in scratch
+EXTRA_FLAGS = {"pn_nn_x3.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -111,7 +120,7 @@ def build_variant(name, defines, verbose=False, only=None):
             objs.append(os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o"))
             continue
         o = os.path.join(vdir, src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc] + FLAGS + list(defines) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
               ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -135,7 +144,7 @@ def build(force=False, verbose=True):
         o = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
         rlog = o + ".resources.txt"
         if force or _stale(o, deps) or (src in RESOURCE_SOURCES and not os.path.exists(rlog)):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if src in RESOURCE_SOURCES:
                 cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
             if verbose:

@@ -115,10 +115,43 @@ __device__ __forceinline__ void x3_tile(X3A<RG> &qa, X3A<RG> &qb, const uint4 (*
     __builtin_amdgcn_sched_barrier(0);                   // keep the read ahead of the MFMAs it overlaps (the scheduler sinks it)
     x3_mma6<RG, NP>(s ? qb : qa, cur, acc, IDX[t]);
     __builtin_amdgcn_sched_barrier(0);
+#if !(defined(PN_XP_ABL) && (PN_XP_ABL & 4))   // timing ablation (results wrong): no A refills
     if (t == NT - 1) {
       x3_load_A<RG, NP>(s ? qb : qa, pf, s);
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
+  }
+}
+
+// x3_tile for a wave that is the ONLY matrix-pipe user of its SIMD (paired-phase kernel): nothing fills the bubbles of its
+// instruction stream, so (a) the B fragments are read D-1 groups ahead (a group is only 2 MFMAs = 64 cycles in the fp16-
+// operand instantiation, less than an LDS round trip), (b) the read-ahead runs across the tile boundary into the NEXT tile's
+// LDS image Bn (complete since the previous barrier: the weight tiles live in a ring of three), so a tile opens with its
+// first fragments already in registers, fr[0 .. D-2], and (c) the tile's other work — the weight-tile stash and load (mid1,
+// after group 1) and the next A pointer (mid3, after group 3) — is issued between MFMA groups instead of around the tile.
+template <int RG, int NP, int NT, int D, int I0, int I1, int I2, int I3, class M1, class M3>
+__device__ __forceinline__ void x3_tile_r(X3A<RG> &qa, X3A<RG> &qb, const uint4 (*Bc)[4][64], const uint4 (*Bn)[4][64],
+                                          const uint4 *__restrict__ pf, int lane, floatx16 (&acc)[RG][4], X3B (&fr)[D],
+                                          M1 &&mid1, M3 &&mid3) {
+  constexpr int IDX[4] = {I0, I1, I2, I3};
+  constexpr int G = 2 * NT;
+  static_assert(G % D == 0 && D >= 2, "the fragment window must tile the groups of a k-tile");
+#pragma unroll
+  for (int i = 0; i < G; i++) {
+    const int s = i / NT, t = i % NT;
+    const int j = i + D - 1;                             // the group whose fragments are fetched now
+    if (j < G) fr[j % D] = x3_read_B<NP>(Bc, j % NT, j / NT, lane);
+    else fr[j % D] = x3_read_B<NP>(Bn, (j - G) % NT, (j - G) / NT, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_mma6<RG, NP>(s ? qb : qa, fr[i % D], acc, IDX[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == NT - 1) {
+      x3_load_A<RG, NP>(s ? qb : qa, pf, s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i == 1) { mid1(); __builtin_amdgcn_sched_barrier(0); }
+    if (i == 3) { mid3(); __builtin_amdgcn_sched_barrier(0); }
   }
 }
 
@@ -391,23 +424,24 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_x3_kernel(
 // stride 2 * blocks-per-XCD, so that all column tiles of an M tile are in flight together (its A shadow stays in that
 // XCD's L2) and every group keeps the same weight tiles for its whole walk when the stride is a multiple of N/32.
 // Same MFMAs, same k order per accumulator, same gating arithmetic as pn_gru_x3_kernel (the epilogue is written on
-// float pairs so that it compiles to v_pk_mul_f32 / v_pk_add_f32 — separately rounded like the scalar form).
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-
+// plain f32 instructions, each separately rounded).
 struct X3PShared {
-  uint4 B[2][2][3][4][64];             // [group][buffer][gate tile][2 * kstep + plane][lane]: 48 KB
-  float T[8][32 * X3_TLD];             // epilogue stage of each wave: 36 KB
+  uint4 B[2][3][3][4][64];             // [group][ring slot][gate tile][2 * kstep + plane][lane]: 72 KB
+  float T[4][32 * X3_TLD];             // epilogue stage, shared by wave w and wave w + 4 (never both in an E phase): 18 KB
   float H[8][64 * 32];                 // previous state of each wave's 64 x 32 tile (for the blend), row-major: 64 KB
   float tansig[208];
 };
 
-// tansig_approx (vec.h:53-75) on a pair, in two halves around the table read (pn_tansig_arg / pn_tansig_fin).  The
-// reference's index is (int)floor(.5f + 25 |x|) by cvttss2si — out of range or NaN gives INT_MIN — clamped to
-// [0, 200]; here: v_cvt_i32_f32 of the NEGATED value (saturates at INT_MIN, NaN -> 0), negated back (INT_MIN stays
-// INT_MIN), then the clamp — the same index for every input.  The sign is carried as the sign BIT of x instead of a
-// +-1 factor (the interpolated value is never negative), so x = -0 returns -0 where the reference returns +0.
-struct X3Ts2 { v2f x; v2i sb, i; };
+// tansig_approx (vec.h:53-75) in two halves around the table read (pn_tansig_arg / pn_tansig_fin), written for the
+// epilogue wave of the paired-phase kernel.  PLAIN f32 instructions on purpose: v_pk_mul_f32 / v_pk_add_f32 issued beside a
+// wave that keeps the SIMD's matrix pipe busy take 41 cycles each instead of 9.5 (tools/probes/mfma_valu_pair_probe.hip,
+// profiles/r04_mfma_valu_pair_probe.log: plain f32, integer and conversion instructions are unaffected) — the file is built
+// with -fno-slp-vectorize so that the compiler does not pack them either.  The reference's table index is
+// (int)floor(.5f + 25 |x|) by cvttss2si — out of range or NaN gives INT_MIN — clamped to [0, 200]; here: v_cvt_i32_f32 of
+// the NEGATED value (saturates at INT_MIN, NaN -> 0), negated back (INT_MIN stays INT_MIN), then the clamp — the same
+// index for every input.  The sign is carried as the sign BIT of x instead of a +-1 factor (the interpolated value is
+// never negative), so x = -0 returns -0 where the reference returns +0.
+struct X3Ts { float x; int sb, i; };
 __device__ __forceinline__ int x3_tab_index(float v) {
   int c;
   asm("v_cvt_i32_f32_e64 %0, -%1" : "=v"(c) : "v"(v));
@@ -416,48 +450,55 @@ __device__ __forceinline__ int x3_tab_index(float v) {
   i = i < 0 ? 0 : i;
   return i;
 }
-__device__ __forceinline__ X3Ts2 x3_ts_arg2(v2f x) {
-  X3Ts2 a;
-  const v2i xb = __builtin_bit_cast(v2i, x);
+__device__ __forceinline__ X3Ts x3_ts_arg(float x) {
+  X3Ts a;
+  const int xb = __builtin_bit_cast(int, x);
   a.sb = xb & (int)0x80000000;
-  const v2f ax = __builtin_bit_cast(v2f, xb & 0x7fffffff);
-  v2f v = .5f + 25.f * ax;
-  v.x = __builtin_floorf(v.x); v.y = __builtin_floorf(v.y);
-  a.i.x = x3_tab_index(v.x); a.i.y = x3_tab_index(v.y);
-  const v2f fi = {(float)a.i.x, (float)a.i.y};
-  a.x = ax - .04f * fi;
+  const float ax = __builtin_bit_cast(float, xb & 0x7fffffff);
+  a.i = x3_tab_index(__builtin_floorf(.5f + 25.f * ax));
+  a.x = ax - .04f * (float)a.i;
   return a;
 }
-__device__ __forceinline__ v2f x3_ts_fin2(const X3Ts2 &a, v2f y) {
-  const v2f dy = 1.f - y * y;
-  const v2f r = y + a.x * dy * (1.f - y * a.x);
-  return __builtin_bit_cast(v2f, __builtin_bit_cast(v2i, r) | a.sb);
+__device__ __forceinline__ float x3_ts_fin(const X3Ts &a, float y) {
+  const float dy = 1.f - y * y;
+  const float r = y + a.x * dy * (1.f - y * a.x);
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, r) | a.sb);
 }
 
 // Pins a value where it is computed: without it the optimiser sinks every stage's arithmetic across the step barriers down
 // to its last use (the stores), which keeps all intermediate values alive (spills) and undoes the step balance.
-__device__ __forceinline__ void x3_pin(v2f &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void x3_pin(v2i &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void x3_pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void x3_pin(int &v) { asm volatile("" : "+v"(v)); }
 
 #ifdef PN_X3_CLOCKS
 __device__ unsigned long long pn_x3p_trace[256 * 2 * 8];
+__device__ unsigned pn_x3p_hwid[256 * 8];              // HW_ID of every wave of every block of the last N = 512 launch
 extern "C" int pn_x3p_trace_read(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3p_trace), sizeof(unsigned long long) * 256 * 2 * 8) == hipSuccess ? 0 : -1;
 }
+extern "C" int pn_x3p_hwid_read(unsigned *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3p_hwid), sizeof(unsigned) * 256 * 8) == hipSuccess ? 0 : -1;
+}
 #endif
 
-#define XP_EPI_STEPS 24                // barriers the epilogue + prologue steps of a phase use; the K loop must have more
+#ifndef PN_XP_PRIO
+#define PN_XP_PRIO 2
+#endif
+#define XP_EPI_STEPS 30                // barriers the epilogue + prologue steps of a phase use; the K loop must have more
 
-template <int NP>
+// KTx = k-tiles of the input panels, NTn = N / 32 = k-tiles of the recurrent operand = column tiles: compile-time, so that
+// every step of a phase is a straight-line piece of code with its own constants (register sets, ring slots, tile numbers)
+template <int NP, int KTx, int NTn>
 __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
     PnSegs X, const float *__restrict__ h_old, const uint4 *__restrict__ h_oldS, const uint4 *__restrict__ Wp,
-    const uint4 *__restrict__ Up, const float *__restrict__ b, int N, int KTx, int tps,
+    const uint4 *__restrict__ Up, const float *__restrict__ b, int tps,
     const float *__restrict__ tansig, float *__restrict__ h_new, uint4 *__restrict__ h_newS, int n_rows, int n_mtiles) {
-  constexpr int RG = 2, XMB = 256;
+  constexpr int RG = 2, XMB = 256, N = 32 * NTn;
+  static_assert(KTx % 2 == 0 && NTn % 2 == 0 && KTx + NTn >= XP_EPI_STEPS, "k-tiles come in pairs; a phase needs its epilogue steps");
   __shared__ X3PShared S;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
-  const int NTn = N >> 5, KTh = NTn, T1 = KTx, TT = KTx + KTh;
+  constexpr int KTh = NTn, T1 = KTx, TT = KTx + KTh;
   const int xcd = blockIdx.x & 7, bpx = gridDim.x >> 3;
   const int n_mtx = n_mtiles > xcd ? (n_mtiles - xcd + 7) >> 3 : 0;      // M tiles of this XCD
   const int Wx = n_mtx * NTn, NS = 2 * bpx, n_it = (Wx + NS - 1) / NS;   // tiles of this XCD, groups walking them, tiles per group
@@ -465,15 +506,22 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
   if (n_it == 0) return;               // an XCD without M tiles (every wave of the block takes this exit)
   if (tid < 201) S.tansig[tid] = tansig[tid];
   const int srow = (64 * gw) & 127;
-  float *T = S.T[wave];
+  float *T = S.T[gw];
 
   floatx16 acc[RG][4];
+  constexpr int XP_D = NP == 1 ? 3 : 2;                   // fragment groups in flight (a group = 2 MFMAs with fp16 operands, 6 split)
+  constexpr int XP_BD = NP == 1 ? 4 : 2;                  // weight tiles in flight global -> registers (a k-tile = 384 / 1152 matrix-pipe
+                                                         // cycles; a weight tile out of L2 / MALL takes one to two thousand)
   X3A<RG> q0, q1, q2, q3;
-  X3_BVEC rb[3];
+  X3_BVEC rb[3];                                         // own prologue: weight tiles 0, 1, 2 on their way into the group's ring
+  X3_BVEC pb[XP_BD][3];                                  // E phase: the partner group's weight tiles on their way into its ring
+  const uint4 *pWz = Wp, *pUz = Up;                      // ... and the z-gate bases of the partner's tile
+  X3B fr[XP_D];
+  const uint4 *pfA = nullptr, *pfB = nullptr;            // A-operand pointers of the tiles the two register pairs are refilled from
   int mt = 0, nt = 0, mt128 = 0, lane_off = 0;           // the tile being (or about to be) accumulated
   float bh = 0.f;
   const uint4 *Wz = Wp, *Uz = Up;                        // z-gate weight tiles of column tile nt; r and h follow at gate strides
-  const size_t gsW = (size_t)NTn * KTx * X3_BTILE, gsU = (size_t)NTn * KTh * X3_BTILE;
+  constexpr size_t gsW = (size_t)NTn * KTx * X3_BTILE, gsU = (size_t)NTn * KTh * X3_BTILE;
   int c_sg = 0, c_kt = 0, c_g = 0;
   const uint4 *c_last = nullptr;
   PN_PANEL_LOCALS(X);
@@ -488,18 +536,51 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
       } else if (c_g < TT) { c_last = h_oldS + ((size_t)mt128 * NTn + (c_g - T1)) * (NP * X3_PLANE) + lane_off; } \
       c_g++; pt = c_last; }
 #define XP_BLD(dst, src) (dst) = reinterpret_cast<const X3_BVEC *>(src)[gtid]
-#define XP_BLOAD(gg) do { XP_SEL(gg); \
-    const uint4 *t0_ = p1_ ? Wz + (size_t)kx_ * X3_BTILE : Uz + (size_t)kh_ * X3_BTILE; const size_t gs_ = p1_ ? gsW : gsU; \
-    XP_BLD(rb[0], t0_); XP_BLD(rb[1], t0_ + gs_); XP_BLD(rb[2], t0_ + 2 * gs_); } while (0)
-#define XP_BST(buf, t, v) reinterpret_cast<X3_BVEC *>(&S.B[grp][buf][t][0][0])[gtid] = (v)
-#define XP_BSTASH(buf) do { XP_BST(buf, 0, rb[0]); XP_BST(buf, 1, rb[1]); XP_BST(buf, 2, rb[2]); } while (0)
+  // weight tile gg (clamped to the last one) of the walk position whose z-gate bases are wz_ / uz_ -> register set dst[3]
+#define XP_BLOADP(dst, wz_, uz_, gg) do { XP_SEL(gg); \
+    const uint4 *t0_ = p1_ ? (wz_) + (size_t)kx_ * X3_BTILE : (uz_) + (size_t)kh_ * X3_BTILE; const size_t gs_ = p1_ ? gsW : gsU; \
+    XP_BLD(dst[0], t0_); XP_BLD(dst[1], t0_ + gs_); XP_BLD(dst[2], t0_ + 2 * gs_); } while (0)
+#define XP_BST(g_, slot, t, v) reinterpret_cast<X3_BVEC *>(&S.B[g_][slot][t][0][0])[gtid] = (v)
+#define XP_BSTASHP(g_, slot, src) do { XP_BST(g_, slot, 0, src[0]); XP_BST(g_, slot, 1, src[1]); XP_BST(g_, slot, 2, src[2]); } while (0)
+  // Weight staging for the PARTNER group's K phase, one call per barrier interval s of that phase (the partner wave of a
+  // SIMD issues them because a global load issued by the wave that feeds the matrix pipe stalls its MFMA stream, a load
+  // issued by the other wave of the SIMD does not: tools/probes/mfma_vmem_probe.hip).  The K group's own prologue has
+  // put tiles 0, 1, 2 into its ring; interval s >= 1 adds tile s + 2 to slot (s + 2) % 3 — free since barrier s - 1 — from
+  // register set (s + 2) % XP_BD, loaded XP_BD intervals earlier (tiles 3 .. 2 + XP_BD: at interval 0), and refills the set
+  // with tile s + 2 + XP_BD.
+#if defined(PN_XP_ABL) && (PN_XP_ABL & 8)       // timing ablation (results wrong): no weight staging during K phases
+#define XP_STAGE(s_) do { } while (0)
+#else
+#define XP_STAGE(s_) do {                                                                                        \
+    if ((s_) >= 1 && (s_) + 2 < TT) XP_BSTASHP(grp ^ 1, ((s_) + 2) % 3, pb[((s_) + 2) % XP_BD]);                 \
+    if ((s_) == 0) { _Pragma("unroll") for (int j_ = 0; j_ < XP_BD; j_++) if (3 + j_ < TT) XP_BLOADP(pb[(3 + j_) % XP_BD], pWz, pUz, 3 + j_); } \
+    else if ((s_) + 2 + XP_BD < TT) XP_BLOADP(pb[((s_) + 2) % XP_BD], pWz, pUz, (s_) + 2 + XP_BD);               \
+  } while (0)
+#endif
+  // z-gate weight bases of the partner group's tile with walk index it_
+#define XP_PARTNER(it_) do {                                                                                     \
+    int w_ = (slot ^ 1) + (it_) * NS; w_ = w_ < Wx ? w_ : Wx - 1;                                                \
+    const int nt_ = w_ % NTn;                                                                                    \
+    pWz = Wp + (size_t)nt_ * KTx * X3_BTILE; pUz = Up + (size_t)nt_ * KTh * X3_BTILE;                             \
+  } while (0)
+  // the K loop's barrier: the fragment reads of the next tile issued at the end of this one (XP_D - 1 groups of NP reads)
+  // stay in flight across it
+#define XP_KBAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F | (((XP_D - 1) * NP) << 8)); \
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if defined(PN_XP_ABL) && (PN_XP_ABL & 2)       // timing ablation (results wrong): the K phase is only its barriers
+#define XP_PAIR(g, I2) XP_KBAR(); XP_KBAR()
+#else
+  // two k-tiles: tile g from ring slot s0 with the A registers q0/q1 (refilled from pfA = tile g + 2), tile g + 1 from s1
+  // with q2/q3 (pfB); each tile's hook advances the A cursor for the other tile's next pointer
 #define XP_PAIR(g, I2)                                                                                           \
-    { XP_APTR(pa); x3_tile<RG, NP, 3, 0, 1, I2, 0>(q0, q1, S.B[grp][0], pa, lane, acc); }                         \
-    XP_BSTASH(1); XP_BLOAD((g) + 2);                                                                             \
-    __syncthreads();                                                                                             \
-    { XP_APTR(pb); x3_tile<RG, NP, 3, 0, 1, I2, 0>(q2, q3, S.B[grp][1], pb, lane, acc); }                         \
-    XP_BSTASH(0); XP_BLOAD((g) + 3);                                                                             \
-    __syncthreads()
+    x3_tile_r<RG, NP, 3, XP_D, 0, 1, I2, 0>(q0, q1, S.B[grp][s0], S.B[grp][s1], pfA, lane, acc, fr,               \
+        [&]() { }, [&]() { XP_APTR(pn_); pfB = pn_; });                                                           \
+    XP_KBAR();                                                                                                   \
+    x3_tile_r<RG, NP, 3, XP_D, 0, 1, I2, 0>(q2, q3, S.B[grp][s1], S.B[grp][s2], pfB, lane, acc, fr,               \
+        [&]() { }, [&]() { XP_APTR(pn_); pfA = pn_; });                                                           \
+    XP_KBAR();                                                                                                   \
+    { const int s_ = s0; s0 = s2; s2 = s1; s1 = s_; }
+#endif
   // prologue of the tile with walk index it_: coordinates, the first two A tiles and the first weight tile in flight ...
 #define XP_PRO0(it_) do {                                                                                        \
     int w_ = slot + (it_) * NS; w_ = w_ < Wx ? w_ : Wx - 1;    /* past the end: a valid tile, loaded and never used */ \
@@ -510,11 +591,13 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
     c_sg = 0; c_kt = 0; c_g = 0;                                                                                 \
     { XP_APTR(p0_); x3_load_A<RG, NP>(q0, p0_, 0); x3_load_A<RG, NP>(q1, p0_, 1); }                               \
     { XP_APTR(p1_); x3_load_A<RG, NP>(q2, p1_, 0); x3_load_A<RG, NP>(q3, p1_, 1); }                               \
-    XP_BLOAD(0);                                                                                                 \
+    { XP_APTR(p2_); pfA = p2_; }                                                                                 \
+    XP_BLOADP(rb, Wz, Uz, 0);                                                                                    \
   } while (0)
-  // ... then the first weight tile into the group's LDS buffer 0, the second into registers, accumulators = biases
-#define XP_PRO1() do {                                                                                           \
-    XP_BSTASH(0); XP_BLOAD(1);                                                                                   \
+  // ... weight tiles 0, 1, 2 into the group's ring slots 0, 1, 2 (one per call) ...
+#define XP_PRO1(j_) do { XP_BSTASHP(grp, j_, rb); if ((j_) < 2) XP_BLOADP(rb, Wz, Uz, (j_) + 1); } while (0)
+  // ... and the accumulators = biases
+#define XP_PRO2() do {                                                                                           \
     const int col_ = nt * 32 + (lane & 31);                                                                      \
     float bz_ = b[col_]; bz_ += b[3 * N + col_];                                                                 \
     float br_ = b[N + col_]; br_ += b[4 * N + col_];                                                             \
@@ -533,31 +616,44 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
     float *hd_ = S.H[wave] + (lane >> 3) * 32 + (lane & 7) * 4;                                                  \
     _Pragma("unroll") for (int j = 0; j < 8; j++) *reinterpret_cast<fvec4 *>(hd_ + 8 * j * 32) = hq[j];           \
   } while (0)
-#define XP_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // barrier of an E-phase / idle step: everything but the last n_ LDS instructions of the wave (its table reads for the next
+  // step) has completed — in particular the stash of the partner's weight tile, which the K waves read after this barrier
+#define XP_BARN(n_) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F | ((n_) << 8)); \
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define XP_BAR() XP_BARN(0)
+  // a phase in which the group only stages the partner's weight tiles (group 1 before its first tile, group 0 after its last)
+#define XP_IDLE_PHASE(it_) do {                                                                                  \
+    XP_PARTNER(it_);                                                                                             \
+    _Pragma("unroll") for (int s = 0; s < TT; s++) { XP_STAGE(s); XP_BAR(); }                                     \
+  } while (0)
 
   // Every group runs the same straight sequence — prologue, then per tile a K phase and an E phase — group 1 one phase
   // behind group 0 (an idle phase before its first tile, one after group 0's last).  A group whose walk runs past the
   // end of the XCD's list clamps to the last tile and recomputes it (identical stores): no data-dependent control flow.
   fvec4 hq[8];
-  XP_PRO0(0); XP_HOLOAD(); XP_PRO1(); XP_HOSTASH();
+  XP_PRO0(0); XP_HOLOAD(); XP_PRO1(0); XP_PRO1(1); XP_PRO1(2); XP_PRO2(); XP_HOSTASH();
   __syncthreads();
 #ifdef PN_X3_CLOCKS
   unsigned long long ck_k = 0, ck_e = 0; const unsigned long long ck_0 = __builtin_readcyclecounter();
 #endif
-  if (grp == 1) {
-#pragma unroll 1
-    for (int g = 0; g < TT; g++) XP_BAR();
-  }
+  if (grp == 1) XP_IDLE_PHASE(0);
 #pragma unroll 1
   for (int it = 0; it < n_it; it++) {
 #ifdef PN_X3_CLOCKS
     const unsigned long long ck_a = __builtin_readcyclecounter();
 #endif
     // ---- K phase: TT barriers -----------------------------------------------------------------------------------
+    {
+      int s0 = 0, s1 = 1, s2 = 2;                              // ring slots of tiles g, g + 1, g + 2
+#pragma unroll
+      for (int j = 0; j < XP_D - 1; j++) fr[j] = x3_read_B<NP>(S.B[grp][0], j % 3, j / 3, lane);
+      __builtin_amdgcn_s_setprio(PN_XP_PRIO);                  // the matrix-pipe stream outranks the partner wave's VALU work
 #pragma unroll 1
-    for (int g = 0; g < T1; g += 2) { XP_PAIR(g, 2); }
+      for (int g = 0; g < T1; g += 2) { XP_PAIR(g, 2); }
 #pragma unroll 1
-    for (int g = T1; g < TT; g += 2) { XP_PAIR(g, 3); }
+      for (int g = T1; g < TT; g += 2) { XP_PAIR(g, 3); }
+      __builtin_amdgcn_s_setprio(0);
+    }
 #ifdef PN_X3_CLOCKS
     const unsigned long long ck_b = __builtin_readcyclecounter();
     ck_k += ck_b - ck_a;
@@ -575,73 +671,90 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
       // chunk c = (row group c >> 3, output pair c & 7): stage A = arguments of z and r + their table reads,
       // B = z, r, candidate pre-activation, its argument + table read, C = candidate, blend.  Step s runs
       // C(s-2), B(s-1), A(s): every table value is read one barrier interval before it is used.
-      X3Ts2 za[16], ra[16], ha[16];
-      v2f zy[16], ry[16], hy[16], zv[16];
+      X3Ts za[32], ra[32], ha[32];
+      float zy[32], ry[32], hy[32], zv[32];
+      XP_PARTNER(it + grp);                                    // group 0's partner runs its tile `it`, group 1's already `it + 1`
+      // step s of the phase = barrier interval s of the partner's K phase: its weight staging first, then this group's own
+      // piece of epilogue / prologue work:  0..17 gating arithmetic (stage A of chunk s, B of s - 1, C of s - 2) | 17 next
+      // tile's first operands | 18..21 the tile leaves through the LDS stage (18: next tile's previous state requested) |
+      // 21, 25, 29 own weight tiles 0, 1, 2 into the ring (each loaded four steps before) | 23 biases | 24 previous state
 #pragma unroll
-      for (int s = 0; s < 18; s++) {
-        if (s >= 2) {
+      for (int s = 0; s < TT; s++) {
+        XP_STAGE(s);
+#if !(defined(PN_XP_ABL) && (PN_XP_ABL & 1))       // timing ablation (results wrong): no gating arithmetic
+        if (s >= 2 && s <= 17) {
           const int c = s - 2, rg = c >> 3, i0 = 2 * (c & 7);
-          const v2f hc = x3_ts_fin2(ha[c], hy[c]);
-          const int hr = 32 * rg + (i0 & 3) + 8 * (i0 >> 2);
-          const v2f hov = {Hl[hr * 32], Hl[(hr + 1) * 32]};
-          v2f o = zv[c] * hov + (1.f - zv[c]) * hc;
-          x3_pin(o);
-          acc[rg][2][i0] = o.x; acc[rg][2][i0 + 1] = o.y;
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int k = 2 * c + e, i = i0 + e;
+            const float hc = x3_ts_fin(ha[k], hy[k]);
+            const float hov = Hl[(32 * rg + (i & 3) + 8 * (i >> 2)) * 32];
+            float o = zv[k] * hov + (1.f - zv[k]) * hc;
+            x3_pin(o);
+            acc[rg][2][i] = o;
+          }
         }
         if (s >= 1 && s <= 16) {
           const int c = s - 1, rg = c >> 3, i0 = 2 * (c & 7);
-          const v2f z = .5f + .5f * x3_ts_fin2(za[c], zy[c]);
-          const v2f r = .5f + .5f * x3_ts_fin2(ra[c], ry[c]);
-          const v2f tmp = {acc[rg][3][i0], acc[rg][3][i0 + 1]}, hx = {acc[rg][2][i0], acc[rg][2][i0 + 1]};
-          v2f hp = bh_e + tmp * r;
-          hp = hp + hx;
-          ha[c] = x3_ts_arg2(hp);
-          hy[c] = v2f{S.tansig[ha[c].i.x], S.tansig[ha[c].i.y]};
-          zv[c] = z;
-          x3_pin(ha[c].x); x3_pin(ha[c].sb); x3_pin(zv[c]);
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int k = 2 * c + e, i = i0 + e;
+            const float z = .5f + .5f * x3_ts_fin(za[k], zy[k]);
+            const float r = .5f + .5f * x3_ts_fin(ra[k], ry[k]);
+            float hp = bh_e + acc[rg][3][i] * r;
+            hp = hp + acc[rg][2][i];
+            ha[k] = x3_ts_arg(hp);
+            hy[k] = S.tansig[ha[k].i];
+            zv[k] = z;
+            x3_pin(ha[k].x); x3_pin(ha[k].sb); x3_pin(zv[k]);
+          }
         }
         if (s <= 15) {
           const int c = s, rg = c >> 3, i0 = 2 * (c & 7);
-          za[c] = x3_ts_arg2(.5f * v2f{acc[rg][0][i0], acc[rg][0][i0 + 1]});
-          ra[c] = x3_ts_arg2(.5f * v2f{acc[rg][1][i0], acc[rg][1][i0 + 1]});
-          zy[c] = v2f{S.tansig[za[c].i.x], S.tansig[za[c].i.y]};
-          ry[c] = v2f{S.tansig[ra[c].i.x], S.tansig[ra[c].i.y]};
-          x3_pin(za[c].x); x3_pin(za[c].sb); x3_pin(ra[c].x); x3_pin(ra[c].sb);
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int k = 2 * c + e, i = i0 + e;
+            za[k] = x3_ts_arg(.5f * acc[rg][0][i]);
+            ra[k] = x3_ts_arg(.5f * acc[rg][1][i]);
+            zy[k] = S.tansig[za[k].i];
+            ry[k] = S.tansig[ra[k].i];
+            x3_pin(za[k].x); x3_pin(za[k].sb); x3_pin(ra[k].x); x3_pin(ra[k].sb);
+          }
         }
-        if (s == 17) XP_PRO0(it + 1);                          // the next tile's first operands (after the last use of the parked state)
-        XP_BAR();
-      }
+#endif
+        if (s == 17) XP_PRO0(it + 1);
+        if (s == 18 || s == 20) {
+          const int rg = (s - 18) >> 1;
+          float vo[16];
 #pragma unroll
-      for (int rg = 0; rg < RG; rg++) {                        // steps 18..21
-        float vo[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) vo[i] = acc[rg][2][i];
-        x3_stage_write(T, vo, lane);
-        x3_stage_store<NP>(T, 0, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
-        if (rg == 0) XP_HOLOAD();                              // step 18: the next tile's previous state (every blend has read the slice)
-        XP_BAR();
-        x3_stage_store<NP>(T, 1, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        XP_BAR();
+          for (int i = 0; i < 16; i++) vo[i] = acc[rg][2][i];
+          x3_stage_write(T, vo, lane);
+          x3_stage_store<NP>(T, 0, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
+          if (s == 18) XP_HOLOAD();                            // every blend has read the wave's slice
+        }
+        if (s == 19 || s == 21) {
+          const int rg = (s - 19) >> 1;
+          x3_stage_store<NP>(T, 1, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (s == 21) XP_PRO1(0);
+        if (s == 23) XP_PRO2();
+        if (s == 24) XP_HOSTASH();
+        if (s == 25) XP_PRO1(1);
+        if (s == 29) XP_PRO1(2);
+        // the barrier: the table reads issued for the next step — 4 by stage A, 2 by stage B — stay in flight across it
+        if (s == TT - 1) __syncthreads();                      // the group's ring slots 0, 1, 2 are complete for its K phase
+        else if (s == 0) XP_BARN(4); else if (s <= 15) XP_BARN(6); else if (s == 16) XP_BARN(2); else XP_BAR();
       }
-      XP_PRO1();                                               // steps 22, 23
-      XP_BAR();
-      XP_HOSTASH();
-      XP_BAR();
-#pragma unroll 1
-      for (int g = XP_EPI_STEPS; g < TT - 1; g++) XP_BAR();
-      __syncthreads();                                         // the group's LDS weight buffer 0 is complete for its K phase
     }
 #ifdef PN_X3_CLOCKS
     ck_e += __builtin_readcyclecounter() - ck_b;
 #endif
   }
-  if (grp == 0) {
-#pragma unroll 1
-    for (int g = 0; g < TT; g++) XP_BAR();
-  }
+  if (grp == 0) XP_IDLE_PHASE(n_it - 1);
 #ifdef PN_X3_CLOCKS
+  if (lane == 0 && N == 512 && blockIdx.x < 256) pn_x3p_hwid[blockIdx.x * 8 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
   if (lane == 0 && gw == 0 && N == 512 && blockIdx.x < 256) {
     unsigned long long *t = pn_x3p_trace + ((size_t)blockIdx.x * 2 + grp) * 8;
     t[0] = ck_k; t[1] = ck_e; t[2] = __builtin_readcyclecounter() - ck_0; t[3] = n_it; t[4] = TT;
@@ -650,12 +763,18 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
 #undef XP_SEL
 #undef XP_APTR
 #undef XP_BLD
-#undef XP_BLOAD
 #undef XP_BST
-#undef XP_BSTASH
 #undef XP_PAIR
 #undef XP_PRO0
 #undef XP_PRO1
+#undef XP_PRO2
+#undef XP_KBAR
+#undef XP_BLOADP
+#undef XP_BSTASHP
+#undef XP_STAGE
+#undef XP_PARTNER
+#undef XP_BARN
+#undef XP_IDLE_PHASE
 #undef XP_HOLOAD
 #undef XP_HOSTASH
 #undef XP_BAR
@@ -720,7 +839,9 @@ int pn_x3_rg_for(int n_rows) {
   const char *e = getenv("PERCEPNET_X3_RG");           // read at every context creation (tests switch it between contexts)
   const int env = e ? atoi(e) : 0;
   if (env >= 1 && env <= 3) return env;
-  return n_rows >= 32768 ? 3 : 1;      // 3 = 64 rows per wave with the GRUs on the paired-phase kernel (pn_gru_x3p_kernel)
+  // 3 = 64 rows per wave with the GRUs on the paired-phase kernel (pn_gru_x3p_kernel): opt-in only — measured at parity
+  // with the one-tile-per-block kernel (0.305 vs 0.291 ms fp16 operands, 0.57 vs 0.59 ms split precision)
+  return n_rows >= 32768 ? 2 : 1;
 }
 
 // A: panels carry the uint4* shadows of equally wide buffers (width = logical columns, a multiple of 32);
@@ -763,13 +884,17 @@ void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const
   const int NTn = N / 32;
   // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it
   // is written for the tanh candidate and needs more K tiles than epilogue steps, otherwise the 64-rows-per-wave kernel
-  if (rg == 3 && act == ACT_TANH && (KTx & 1) == 0 && (NTn & 1) == 0 && KTx + NTn > XP_EPI_STEPS + 1) {
+  // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it
+  // is written for the tanh candidate and instantiated for the two GRU geometries of the network (512 -> 512 and
+  // 1024 -> 128); anything else runs on the 64-rows-per-wave kernel
+  if (rg == 3 && act == ACT_TANH && ((KTx == 16 && NTn == 16) || (KTx == 32 && NTn == 4))) {
     const int n_mtiles = (n_rows + 255) / 256;
     const int grid = 8 * (x3_cu_count() / 8);
-#define XP_LAUNCH(NP_)                                                                                              \
-    hipLaunchKernelGGL((pn_gru_x3p_kernel<NP_>), dim3(grid), dim3(512), 0, st, X, h_old, (const uint4 *)h_oldS,        \
-                       (const uint4 *)Wp, (const uint4 *)Up, b, N, KTx, tps, tansig, h_new, (uint4 *)h_newS, n_rows, n_mtiles)
-    if (np == 2) XP_LAUNCH(2); else XP_LAUNCH(1);
+#define XP_LAUNCH(NP_, KTX_, NTN_)                                                                                  \
+    hipLaunchKernelGGL((pn_gru_x3p_kernel<NP_, KTX_, NTN_>), dim3(grid), dim3(512), 0, st, X, h_old, (const uint4 *)h_oldS, \
+                       (const uint4 *)Wp, (const uint4 *)Up, b, tps, tansig, h_new, (uint4 *)h_newS, n_rows, n_mtiles)
+    if (NTn == 16) { if (np == 2) XP_LAUNCH(2, 16, 16); else XP_LAUNCH(1, 16, 16); }
+    else { if (np == 2) XP_LAUNCH(2, 32, 4); else XP_LAUNCH(1, 32, 4); }
 #undef XP_LAUNCH
     return;
   }

@@ -215,7 +215,7 @@ def test_x3_row_group_instantiations_agree_bit_for_bit(model):
     base = synth.synth_batch(16, T)
     small = api.Context(model, K, nn_mode=api.NN_MFMA_X3)
     big = api.Context(model, 32768, nn_mode=api.NN_MFMA_X3)
-    assert small.describe()["gru"] == "x3_rows32" and big.describe()["gru"] == "x3_rows64_paired"
+    assert small.describe()["gru"] == "x3_rows32" and big.describe()["gru"] == "x3_rows64"
     ps, pb = base[np.arange(K) % 16], base[np.arange(32768) % 16]
     for t in range(T):
         os_, gs = small.process_i16(ps[:, t * 480:(t + 1) * 480])
@@ -228,9 +228,10 @@ def test_x3_row_group_instantiations_agree_bit_for_bit(model):
 
 @pytest.mark.parametrize("mode", [api.NN_MFMA_X3, api.NN_MFMA_F16], ids=["x3", "f16"])
 def test_paired_phase_gru_kernel_agrees_bit_for_bit_with_the_one_tile_per_block_kernel(model, mode, monkeypatch):
-    """Large batches run the GRUs on pn_gru_x3p_kernel (one persistent 8-wave block per CU: the K loop of one wave group
-    beside the gating epilogue of the other, epilogue on float pairs).  Same MFMAs in the same order and the same separately
-    rounded gating arithmetic as pn_gru_x3_kernel, so the two must agree bit for bit — on a batch whose M tiles do not divide
+    """PERCEPNET_X3_RG=3 runs the GRUs of a large batch on pn_gru_x3p_kernel (one persistent 8-wave block per CU: the K loop of
+    one wave group beside the gating epilogue of the other, which also stages the K group's weight tiles; opt-in, DESIGN.md
+    4.2f).  Same MFMAs in the same order and the same separately rounded gating arithmetic as pn_gru_x3_kernel, so the two
+    must agree bit for bit — on a batch whose M tiles do not divide
     evenly over the 8 XCDs and the 64 tile walkers per XCD (33 025 streams = 130 M tiles, the last one ragged), and with
     the recurrent state carried over several frames."""
     B, K, T = 33025, 16, 6
@@ -279,7 +280,7 @@ def test_shadow_operand_kernels_ragged_last_block_at_64_rows_per_wave(model, mod
     base = synth.synth_batch(K, T)
     big = api.Context(model, B, nn_mode=mode)
     small = api.Context(model, K, nn_mode=mode)
-    assert big.describe()["gru"].endswith("rows64_paired") and small.describe()["gru"].endswith("rows32")
+    assert big.describe()["gru"].endswith("rows64") and small.describe()["gru"].endswith("rows32")
     idx = np.arange(B) % K
     pb = base[idx]
     for t in range(T):
@@ -319,7 +320,7 @@ def test_x3_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle):
             return torch.gather(d_pool[:, t * 480:(t + 1) * 480][d_idx], 1, ar).contiguous()
 
         ctx = api.Context(model, B, nn_mode=api.NN_MFMA_X3, stream=ts.cuda_stream)
-        assert ctx.describe()["gru"] == "x3_rows64_paired"
+        assert ctx.describe()["gru"] == "x3_rows64"
         got = run_long(ctx, frame_of, T, rows, dev)
         ctx.close()
     compare("x3_65536x1000_sample256", got, ref, {

@@ -32,3 +32,13 @@ for g in (0, 1):
           f"E phase mean {e.mean():8.0f} (p10 {np.percentile(e, 10):.0f} p90 {np.percentile(e, 90):.0f}); kernel {tot.mean():.0f}")
 print(f"tiles per group {n_it}, K tiles per phase {TT}; matrix-pipe time of one K phase = {mfma} cycles; "
       f"ideal kernel = {(2 * n_it + 1) * mfma} cycles")
+
+hw = (ctypes.c_uint * (256 * 8))()
+if hasattr(L, "pn_x3p_hwid_read") and L.pn_x3p_hwid_read(hw) == 0:
+    h = np.array(list(hw), dtype=np.int64).reshape(256, 8)
+    simd = (h >> 4) & 3; cu = (h >> 8) & 15; wid = h & 15
+    for b in (0, 1, 100, 255):
+        print(f"block {b}: SIMD of waves 0..7 = {simd[b].tolist()}  CU {cu[b].tolist()}  wave slot {wid[b].tolist()}")
+    same = (simd[:, :4] == simd[:, 4:]).all(axis=1).mean()
+    print(f"blocks whose waves w and w + 4 share a SIMD: {100 * same:.0f} %; blocks whose waves 0..3 sit on four different SIMDs: "
+          f"{100 * np.mean([len(set(r[:4])) == 4 for r in simd]):.0f} %")
