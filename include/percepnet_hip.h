@@ -29,6 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and its pop (plus the
+   reference's nine C++-mangled names, csrc/rnnoise_compat.cpp) are exported.  Harmless for callers. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define PN_FRAME_SIZE 480      /* reference denoise.cpp:19 */
 #define PN_NB_BANDS 34         /* reference denoise.cpp:35 */
@@ -206,6 +211,9 @@ void rnnoise_model_free_c(RNNModel *model);
    PERCEPNET_STRICT=1|0, device PERCEPNET_DEVICE) and written back, so the caller sees the reference's semantics. */
 void rnnoise_compute_rnn_c(RNNState *rnn, float *gains, float *strengths, const float *input);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -17,12 +17,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpercepnet_hip.so")
 RUN = os.path.join(LIBDIR, "percepnet_run")
+EXPORT_MAP = os.path.join(CSRC, "libpercepnet_hip.map")    # ld version script: the export list (everything else is local)
 RELINKED = os.path.join(LIBDIR, "percepNet_run_relinked")    # reference src/main.cpp, untouched, linked against LIB
 REFERENCE_SRC = os.environ.get("PERCEPNET_REFERENCE_SRC", "/root/reference/src")
-SOURCES = ["pn_tables.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_targets.hip", "pn_context.cpp",
+SOURCES = ["pn_tables.cpp", "pn_model.cpp", "pn_pack.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_targets.hip", "pn_context.cpp",
            "pn_featgen.cpp", "rnnoise_compat.cpp"]
 # percepnet_run.cpp / percepnet_featgen.cpp (the CLIs) are linked separately against the library
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -127,7 +128,7 @@ def build_variant(name, defines, verbose=False, only=None):
         subprocess.check_call(cmd)
         objs.append(o)
     lib = os.path.join(vdir, "libpercepnet_hip.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORT_MAP, "-o", lib] + objs)
     return lib
 
 
@@ -163,8 +164,8 @@ def build(force=False, verbose=True):
     bad = check_resources(resources)
     if bad:
         raise RuntimeError("register hygiene gate (build.RESOURCE_LIMITS) failed:\n  " + "\n  ".join(bad))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(LIB, objs + [EXPORT_MAP]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORT_MAP, "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1,9 +1,12 @@
 // Internal shared definitions for libpercepnet_hip (host + device).
 #pragma once
-#include <hip/hip_runtime.h>
+#ifndef PN_NO_HIP                 // PN_NO_HIP: the HIP-free host pieces (pn_model.cpp, pn_pack.cpp, pn_tables.cpp) built alone, e.g.
+#include <hip/hip_runtime.h>      // by the sanitizer harness tests/c/host_sanitize.cpp with plain g++
+#endif
 #include <stdint.h>
 #include <stddef.h>
 
+#define PN_EXPORT __attribute__((visibility("default")))   // the library is built with -fvisibility=hidden
 #define PN_FRAME 480
 #define PN_WINDOW 960
 #define PN_FREQ 481
@@ -43,7 +46,7 @@ struct PnTables {
 };
 #define PN_BAND_LAYOUT_FLOATS 920   // total size of that layout for the 34-band table of erbband.h (checked in pn_build_tables)
 
-void pn_build_tables(PnTables *t);
+int pn_build_tables(PnTables *t);          // 0, or -1 with pn_set_error (a build whose table layout and kernels disagree)
 
 // Network geometry (rnn_train.py:105-121 / rnn.cpp:42-81)
 enum { PN_L_FC, PN_L_CONV1, PN_L_CONV2, PN_L_GRU1, PN_L_GRU2, PN_L_GRU3, PN_L_GRU_GB, PN_L_GRU_RB,
@@ -55,20 +58,37 @@ struct PnLayerHost {
   const float *bias, *w, *rw;   // host pointers into the model's own copy (nnet_data.h layouts)
 };
 
+struct PnLayerSrc { int kind, nin, nn, ks, act, reset_after; const float *bias, *w, *rw; };   // one layer's arrays, wherever they live
+
 struct pn_model {
   PnLayerHost L[PN_NLAYERS];
   float *storage;               // one malloc holding every array
   size_t n_floats;
 };
 
+#ifndef PN_NO_HIP
 #define PN_HIP_CHECK(expr)                                                              \
   do {                                                                                  \
     hipError_t _e = (expr);                                                             \
     if (_e != hipSuccess) { pn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return -1; } \
   } while (0)
 
+#endif
 void pn_set_error(const char *fmt, ...);
 
+// pn_model.cpp: the fixed topology and the size of a layer's arrays in the nnet_data.h layout
+struct PnGeom { int kind, nin, nn, ks; };
+extern const PnGeom pn_kGeom[];
+size_t pn_layer_floats(int kind, int nin, int nn, int ks, size_t *nb, size_t *nw, size_t *nr);
+// pn_pack.cpp: host-side re-packing of the weight matrices for the fp32 MFMA kernels
+size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
+void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
+int pn_ct_padded(int ncols, int ct_round);
+int pn_dense_nt(int N);
+size_t pn_packed_floats_n16(int K, int ncols);
+void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);
+
+#ifndef PN_NO_HIP
 // Every entry point runs on the context's device and leaves the caller's current device as it found it (callers
 // hand in torch data_ptr()s from a thread whose current device torch manages).
 struct DeviceGuard {
@@ -81,3 +101,5 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
 #define PN_ON_DEVICE(c) DeviceGuard _dg((c)->device); if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", (c)->device); return -1; }
+
+#endif

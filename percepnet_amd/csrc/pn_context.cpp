@@ -17,113 +17,7 @@
 #include "pn_launch.h"
 #include "pn_selftest_golden.h"
 
-int g_pn_dsp_grid_cap = 0;
-
-// ---- errors -----------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-void pn_set_error(const char *fmt, ...) {
-  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
-}
-extern "C" const char *pn_last_error(void) { return g_err; }
-extern "C" const char *pn_version(void) { return "percepnet_hip 0.2 (gfx950)"; }
 extern "C" int pn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
-
-// ---- models -------------------------------------------------------------------------------------------
-static const struct { int kind, nin, nn, ks; } kGeom[PN_NLAYERS] = {
-  {PN_KIND_DENSE, 70, 128, 1}, {PN_KIND_CONV1D, 128, 512, 5}, {PN_KIND_CONV1D, 512, 512, 3},
-  {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1}, {PN_KIND_GRU, 512, 512, 1},
-  {PN_KIND_GRU, 1024, 128, 1}, {PN_KIND_DENSE, 2560, 34, 1}, {PN_KIND_DENSE, 128, 34, 1}};
-
-static size_t layer_floats(int kind, int nin, int nn, int ks, size_t *nb, size_t *nw, size_t *nr) {
-  *nb = kind == PN_KIND_GRU ? 6 * (size_t)nn : (size_t)nn;
-  *nw = (size_t)nin * ks * nn * (kind == PN_KIND_GRU ? 3 : 1);
-  *nr = kind == PN_KIND_GRU ? (size_t)nn * 3 * nn : 0;
-  return *nb + *nw + *nr;
-}
-
-static int check_geometry(int li, int kind, int nin, int nn, int ks) {
-  if (kind != kGeom[li].kind || nin != kGeom[li].nin || nn != kGeom[li].nn || ks != kGeom[li].ks) {
-    pn_set_error("layer %d: geometry %d/%d/%d/%d differs from the PercepNet topology (rnn.cpp:42-81 hard-codes it)",
-                 li, kind, nin, nn, ks);
-    return -1;
-  }
-  return 0;
-}
-
-struct LayerSrc { int kind, nin, nn, ks, act, reset_after; const float *bias, *w, *rw; };
-
-static pn_model *model_from_sources(const LayerSrc *src) {
-  size_t total = 0;
-  for (int li = 0; li < PN_NLAYERS; li++) {
-    size_t nb, nw, nr;
-    if (check_geometry(li, src[li].kind, src[li].nin, src[li].nn, src[li].ks)) return NULL;
-    if (src[li].kind == PN_KIND_GRU && !src[li].reset_after) { pn_set_error("only reset_after GRUs are supported (dump_percepnet.py:94-98)"); return NULL; }
-    total += layer_floats(src[li].kind, src[li].nin, src[li].nn, src[li].ks, &nb, &nw, &nr);
-  }
-  pn_model *m = (pn_model *)calloc(1, sizeof(pn_model));
-  m->storage = (float *)malloc(total * sizeof(float));
-  m->n_floats = total;
-  float *p = m->storage;
-  for (int li = 0; li < PN_NLAYERS; li++) {
-    size_t nb, nw, nr;
-    layer_floats(src[li].kind, src[li].nin, src[li].nn, src[li].ks, &nb, &nw, &nr);
-    PnLayerHost &L = m->L[li];
-    L.kind = src[li].kind; L.nin = src[li].nin; L.nn = src[li].nn; L.ks = src[li].ks; L.act = src[li].act;
-    L.reset_after = src[li].reset_after;
-    memcpy(p, src[li].bias, nb * 4); L.bias = p; p += nb;
-    memcpy(p, src[li].w, nw * 4); L.w = p; p += nw;
-    if (nr) { memcpy(p, src[li].rw, nr * 4); L.rw = p; p += nr; } else L.rw = NULL;
-  }
-  return m;
-}
-
-extern "C" pn_model *pn_model_from_rnnmodel(const RNNModel *r) {
-  if (!r) { pn_set_error("NULL RNNModel"); return NULL; }
-  LayerSrc s[PN_NLAYERS];
-  const DenseLayer *d[3] = {r->fc, r->fc_gb, r->fc_rb};
-  const int di[3] = {PN_L_FC, PN_L_FC_GB, PN_L_FC_RB};
-  for (int i = 0; i < 3; i++) s[di[i]] = {PN_KIND_DENSE, d[i]->nb_inputs, d[i]->nb_neurons, 1, d[i]->activation, 0, d[i]->bias, d[i]->input_weights, NULL};
-  const Conv1DLayer *c[2] = {r->conv1, r->conv2};
-  for (int i = 0; i < 2; i++) s[PN_L_CONV1 + i] = {PN_KIND_CONV1D, c[i]->nb_inputs, c[i]->nb_neurons, c[i]->kernel_size, c[i]->activation, 0, c[i]->bias, c[i]->input_weights, NULL};
-  const GRULayer *g[5] = {r->gru1, r->gru2, r->gru3, r->gru_gb, r->gru_rb};
-  for (int i = 0; i < 5; i++) s[PN_L_GRU1 + i] = {PN_KIND_GRU, g[i]->nb_inputs, g[i]->nb_neurons, 1, g[i]->activation, g[i]->reset_after, g[i]->bias, g[i]->input_weights, g[i]->recurrent_weights};
-  return model_from_sources(s);
-}
-
-extern "C" pn_model *pn_model_from_blob(const void *blob, size_t nbytes) {
-  const unsigned char *p = (const unsigned char *)blob;
-  if (!p || nbytes < 8 || memcmp(p, "PNW1", 4) != 0) { pn_set_error("not a PNW1 weight container"); return NULL; }
-  uint32_t n; memcpy(&n, p + 4, 4);
-  if (n != PN_NLAYERS) { pn_set_error("PNW1: %u layers, expected %d", n, PN_NLAYERS); return NULL; }
-  // arrays inside the blob are only 4-byte aligned relative to its start; copy through an
-  // aligned staging buffer
-  std::vector<float> stage((nbytes + 3) / 4);
-  LayerSrc s[PN_NLAYERS];
-  size_t off = 8, fo = 0;
-  for (uint32_t li = 0; li < n; li++) {
-    if (off + 24 > nbytes) { pn_set_error("PNW1: truncated"); return NULL; }
-    uint32_t h[6]; memcpy(h, p + off, 24); off += 24;
-    size_t nb, nw, nr;
-    size_t tot = layer_floats(h[0], h[1], h[2], h[3], &nb, &nw, &nr);
-    if (h[0] > 2 || off + tot * 4 > nbytes) { pn_set_error("PNW1: truncated or bad layer %u", li); return NULL; }
-    memcpy(&stage[fo], p + off, tot * 4); off += tot * 4;
-    s[li] = {(int)h[0], (int)h[1], (int)h[2], (int)h[3], (int)h[4], (int)h[5], &stage[fo], &stage[fo + nb], nr ? &stage[fo + nb + nw] : NULL};
-    fo += tot;
-  }
-  if (off != nbytes) { pn_set_error("PNW1: %zu trailing bytes", nbytes - off); return NULL; }
-  return model_from_sources(s);
-}
-
-extern "C" pn_model *pn_model_from_file(FILE *f) {
-  if (!f) { pn_set_error("NULL FILE"); return NULL; }
-  std::vector<unsigned char> buf;
-  unsigned char tmp[1 << 16];
-  size_t n;
-  while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-  return pn_model_from_blob(buf.data(), buf.size());
-}
-
-extern "C" void pn_model_free(pn_model *m) { if (m) { free(m->storage); free(m); } }
 
 // ---- contexts -----------------------------------------------------------------------------------------
 enum { KF_FRONTEND, KF_FC, KF_CONV1, KF_CONV2, KF_GRU512, KF_GRU_RB, KF_FC_GB, KF_FC_RB, KF_BACKEND, KF_FE_SPEC_IN, KF_FE_PITCH,
@@ -156,6 +50,7 @@ struct pn_ctx {
   float2 *yring, *Ps;              // yring: [6][B][400] look-ahead spectra (X of frame t = slot (t+1)%6)
   float *eyring;                   // [6][B][36] look-ahead band energies
   bool postfilter = false;         // optional envelope post-filter in the back end (pn_ctx_set_postfilter)
+  int dsp_grid_cap = 0;            // > 0 only in the DSP self-test's temporary context: its DSP launches use that many blocks
   int *last_period, *silence;
   std::vector<void *> allocs;
   bool profiling;
@@ -309,8 +204,8 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   const size_t B = n_streams, Bp = c->Bp;
   {
     PnTables *ht = new PnTables();
-    pn_build_tables(ht);
-    int rc = dev_alloc(c, (void **)&c->tables, sizeof(PnTables), false);
+    int rc = pn_build_tables(ht);
+    if (!rc) rc = dev_alloc(c, (void **)&c->tables, sizeof(PnTables), false);
     if (!rc && hipMemcpyAsync(c->tables, ht, sizeof(PnTables), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1;
     if (!rc) rc = upload(c, &c->tansig, ht->tansig, 208);
     hipStreamSynchronize(c->stream);
@@ -347,7 +242,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
     const PnLayerHost &H = model->L[li];
     c->geom[li] = H; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL;
     size_t nb, nw, nr;
-    layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
+    pn_layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
     if (upload(c, &c->L[li].bias, H.bias, nb)) goto fail;
     if (nn_mode == PN_NN_STRICT) {
       if (upload(c, &c->L[li].w, H.w, nw)) goto fail;
@@ -561,28 +456,29 @@ static void launch_rnn(pn_ctx *c) {
 static std::mutex g_selftest_mu;
 static std::map<std::tuple<int, int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
 
+pn_model *pn_model_from_sources(const struct PnLayerSrc *src);
 static pn_model *selftest_model() {
   static std::vector<float> store;
-  LayerSrc s[PN_NLAYERS];
+  PnLayerSrc s[PN_NLAYERS];
   size_t total = 0, nb, nw, nr;
-  for (int li = 0; li < PN_NLAYERS; li++) total += layer_floats(kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, &nb, &nw, &nr);
+  for (int li = 0; li < PN_NLAYERS; li++) total += pn_layer_floats(pn_kGeom[li].kind, pn_kGeom[li].nin, pn_kGeom[li].nn, pn_kGeom[li].ks, &nb, &nw, &nr);
   store.resize(total);
   unsigned x = 2463534242u;
   size_t off = 0;
   static const int act[PN_NLAYERS] = {3, 3, 2, 2, 2, 2, 2, 2, 1, 1};        // relu relu tanh tanh*5 sigmoid sigmoid (rnn_train.py:105-121)
   for (int li = 0; li < PN_NLAYERS; li++) {
-    layer_floats(kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, &nb, &nw, &nr);
-    const float bound_w = 1.f / sqrtf((float)(kGeom[li].kind == PN_KIND_GRU ? kGeom[li].nn : kGeom[li].nin * kGeom[li].ks));
+    pn_layer_floats(pn_kGeom[li].kind, pn_kGeom[li].nin, pn_kGeom[li].nn, pn_kGeom[li].ks, &nb, &nw, &nr);
+    const float bound_w = 1.f / sqrtf((float)(pn_kGeom[li].kind == PN_KIND_GRU ? pn_kGeom[li].nn : pn_kGeom[li].nin * pn_kGeom[li].ks));
     for (size_t i = 0; i < nb + nw + nr; i++) {
       x = x * 1664525u + 1013904223u;
       // x3: a good share of the GRU gates and tanh outputs saturate, so the clamped end of the activation table
       // (indices 192..200: a 192-thread block once failed to stage them) is exercised, not only its linear middle
       store[off + i] = ((int)(x >> 8) % 20001 - 10000) * 1e-4f * bound_w * (i < nb ? 1.f : 3.f);
     }
-    s[li] = {kGeom[li].kind, kGeom[li].nin, kGeom[li].nn, kGeom[li].ks, act[li], 1, &store[off], &store[off + nb], nr ? &store[off + nb + nw] : NULL};
+    s[li] = {pn_kGeom[li].kind, pn_kGeom[li].nin, pn_kGeom[li].nn, pn_kGeom[li].ks, act[li], 1, &store[off], &store[off + nb], nr ? &store[off + nb + nw] : NULL};
     off += nb + nw + nr;
   }
-  pn_model *m = model_from_sources(s);
+  pn_model *m = pn_model_from_sources(s);
   store.clear(); store.shrink_to_fit();
   return m;
 }
@@ -642,7 +538,7 @@ static int nn_selftest(pn_ctx *c) {
 // Known-answer self-test of the DSP kernels, the counterpart of nn_selftest (PERCEPNET_SELFTEST=0 skips both).
 // The first context of every (device, front-end family) in a process runs a fixed integer-generated waveform
 // (two triangle waves + LCG noise, quiet and clipping stretches) through a temporary 40-stream context whose DSP
-// launches are capped at ONE block (g_pn_dsp_grid_cap): every stream is fed the same PCM, so the 40 streams of 3 to 10
+// launches are capped at ONE block (pn_ctx::dsp_grid_cap, an argument of the DSP launchers): every stream is fed the same PCM, so the 40 streams of 3 to 10
 // grid-stride rounds must agree with each other word for word, the silence flags of all 14 frames (a full wrap of
 // the 12-frame history ring) and the 70 features of the last frame must equal the CPU oracle's bit patterns stored in
 // pn_selftest_golden.h (tools/make_dsp_selftest_golden.py; the features never touch the network).
@@ -685,7 +581,7 @@ static int dsp_selftest(pn_ctx *c) {
   std::vector<float> feat((size_t)Bt * PN_NFEAT);
   std::vector<int32_t> sil(Bt);
   int rc = 0; std::string msg;
-  g_pn_dsp_grid_cap = 1;
+  t->dsp_grid_cap = 1;
   for (int f = 0; f < PN_SELFTEST_FRAMES && !rc; f++) {
     for (int s = 0; s < Bt; s++) memcpy(&in[(size_t)s * PN_FRAME], &pcm[(size_t)f * PN_FRAME], PN_FRAME * sizeof(int16_t));
     if (pn_process_host_i16(t, in.data(), out.data(), NULL) || pn_ctx_read_features(t, feat.data(), sil.data())) { rc = -1; msg = pn_last_error(); break; }
@@ -699,7 +595,6 @@ static int dsp_selftest(pn_ctx *c) {
         if (w != kSelftestFeat[k]) { rc = -2; msg = "feature " + std::to_string(k) + " of the last frame"; break; }
       }
   }
-  g_pn_dsp_grid_cap = 0;
   pn_ctx_destroy(t); pn_model_free(m);
   if (env && atoi(env) >= 2) fprintf(stderr, "percepnet_hip: DSP self-test device %d front end %d: %s\n", c->device, c->fe_mode, rc ? msg.c_str() : "70 features + 14 silence flags bit-equal to the CPU oracle, 40 streams identical");
   if (rc == -1) { pn_set_error("DSP self-test could not run: %s", msg.c_str()); return -1; }
@@ -717,16 +612,16 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   PN_ON_DEVICE(c);
   if (c->fe_mode == FE_SPLIT) {
     { Scope sc(c, KF_FE_SPEC_IN);
-      pn_launch_fe_spec_in(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring, c->eyring); }
+      pn_launch_fe_spec_in(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f, c->hist, c->yring, c->eyring, c->dsp_grid_cap); }
     { Scope sc(c, KF_FE_PITCH);
-      pn_launch_fe_pitch(c->stream, c->B, c->t, c->hist, c->feat, c->last_period, c->last_gain, nullptr); }
+      pn_launch_fe_pitch(c->stream, c->B, c->t, c->hist, c->feat, c->last_period, c->last_gain, nullptr, c->dsp_grid_cap); }
     { Scope sc(c, KF_FE_SPEC_OUT);
       pn_launch_fe_spec_out(c->stream, c->tables, c->B, c->t, c->hist, c->yring, c->eyring, c->last_period, c->Ps, c->feat,
-                            c->silence, nullptr); }
+                            c->silence, nullptr, c->dsp_grid_cap); }
   } else {
     Scope sc(c, KF_FRONTEND);
     (c->fe_mode == FE_MONO_G2 ? pn_launch_frontend_g2 : pn_launch_frontend)(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f,
-        c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr);
+        c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr, c->dsp_grid_cap);
   }
   launch_rnn(c);
   { Scope sc(c, KF_BACKEND);
@@ -734,7 +629,7 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
     const size_t slot = (size_t)((c->t + 1) % 6);
     const float2 *Xs = c->yring + slot * c->B * PN_SPEC_BINS;
     const float *Ex = c->postfilter ? c->eyring + slot * c->B * 36 : nullptr;      // Ex(t) = Ey_lookahead(t-5)
-    pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, Ex, c->silence, c->synth, d_out, is_i16); }
+    pn_launch_backend(c->stream, c->tables, c->B, Xs, c->Ps, c->gr, Ex, c->silence, c->synth, d_out, is_i16, c->dsp_grid_cap); }
   if (d_gr) PN_HIP_CHECK(hipMemcpyAsync(d_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToDevice, c->stream));
   PN_HIP_CHECK(hipGetLastError());
   c->t++; c->tn++;

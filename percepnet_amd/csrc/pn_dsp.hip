@@ -178,17 +178,17 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
 // ---- launchers -------------------------------------------------------------------------------
 // blocks_per_cu: 2 fills the CUs (80 KB LDS each); 1 leaves half of every CU's LDS/registers free so
 // that an MFMA-bound network kernel of another frame can be co-resident (pipelined mode)
-static inline int pn_dsp_grid(int n_streams, int blocks_per_cu) {
+static inline int pn_dsp_grid(int n_streams, int blocks_per_cu, int grid_cap) {
   const int need = (n_streams + WPB - 1) / WPB;
   const int full = PN_DSP_WAVES_PER_SIMD * 4 / WPB;
-  const int cap = g_pn_dsp_grid_cap > 0 ? g_pn_dsp_grid_cap : 256 * ((blocks_per_cu > 0 && blocks_per_cu < full) ? blocks_per_cu : full);
+  const int cap = grid_cap > 0 ? grid_cap : 256 * ((blocks_per_cu > 0 && blocks_per_cu < full) ? blocks_per_cu : full);
   return need < cap ? need : cap;
 }
 
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const float *ex_postfilter, const int *silence, float *synth_mem, void *out,
-                       int out_is_i16) {
-  const int grid = pn_dsp_grid(n_streams, 0);
+                       int out_is_i16, int grid_cap) {
+  const int grid = pn_dsp_grid(n_streams, 0, grid_cap);
   const dim3 g(grid), b(DSP_THREADS);
   if (ex_postfilter) {
     if (out_is_i16)

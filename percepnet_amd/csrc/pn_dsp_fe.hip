@@ -557,11 +557,11 @@ __global__ __launch_bounds__(FE_THREADS, PN_FE_WAVES_PER_SIMD) void pn_frontend_
 // ---- launcher ---------------------------------------------------------------------------------
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
                         int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
-                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
+                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap) {
   const int need = (n_streams + FE_SPB - 1) / FE_SPB;
   const int cap = 256 * (16 / FE_SPB);                 // LDS-resident blocks on 256 CUs
   int grid = need < cap ? need : cap;                  // grid-stride
-  if (g_pn_dsp_grid_cap > 0 && grid > g_pn_dsp_grid_cap) grid = g_pn_dsp_grid_cap;
+  if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
   const int frame_t = (int)(frame % PN_HIST_FRAMES);
   const int slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
   if (in_is_i16)

@@ -563,11 +563,11 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
 }
 
 void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const float *hist, float *feat, int *last_period,
-                        float *last_gain, float *aux) {
+                        float *last_gain, float *aux, int grid_cap) {
   const int need = (n_streams + FP_SPB - 1) / FP_SPB;
   const int cap = 256 * 2;                               // two LDS-resident blocks on each of 256 CUs
   int grid = need < cap ? need : cap;
-  if (g_pn_dsp_grid_cap > 0 && grid > g_pn_dsp_grid_cap) grid = g_pn_dsp_grid_cap;
+  if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
   static const int stagger = getenv("PERCEPNET_FP_STAGGER") ? atoi(getenv("PERCEPNET_FP_STAGGER")) : 0;
   // only worth it when a block walks several stream groups (the delay is paid once per launch)
   hipLaunchKernelGGL(pn_fe_pitch_kernel, dim3(grid), dim3(FP_THREADS), 0, st, n_streams, (int)(frame % PN_HIST_FRAMES), hist,

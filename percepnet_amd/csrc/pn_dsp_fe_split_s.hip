@@ -276,34 +276,34 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
-static int fs_grid(int n_streams, int blocks_per_cu) {
+static int fs_grid(int n_streams, int blocks_per_cu, int grid_cap) {
   const int need = (n_streams + FS_WPB - 1) / FS_WPB;
-  const int cap = g_pn_dsp_grid_cap > 0 ? g_pn_dsp_grid_cap : 256 * blocks_per_cu;   // resident 4-wave blocks on 256 CUs
+  const int cap = grid_cap > 0 ? grid_cap : 256 * blocks_per_cu;   // resident 4-wave blocks on 256 CUs
   return need < cap ? need : cap;
 }
 void pn_launch_fe_spec_in(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
-                          long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring) {
+                          long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, int grid_cap) {
   const int frame_t = (int)(frame % PN_HIST_FRAMES), slot_w = (int)(frame % 6);
   if (in_is_i16)
-    hipLaunchKernelGGL(pn_fe_spec_in_kernel<int16_t>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_fe_spec_in_kernel<int16_t>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN, grid_cap)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
                        slot_w, (const int16_t *)in, in_stride, i16_scale, hist, yring, eyring);
   else
-    hipLaunchKernelGGL(pn_fe_spec_in_kernel<float>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
+    hipLaunchKernelGGL(pn_fe_spec_in_kernel<float>, dim3(fs_grid(n_streams, PN_FS_WAVES_IN, grid_cap)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t,
                        slot_w, (const float *)in, in_stride, i16_scale, hist, yring, eyring);
 }
 void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const float *hist,
                            const float2 *yring, const float *eyring, const int *last_period, float2 *Ps, float *feat,
-                           int *silence, float *aux) {
+                           int *silence, float *aux, int grid_cap) {
   const int frame_t = (int)(frame % PN_HIST_FRAMES), slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
-  hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams, PN_FS_WAVES_OUT)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
+  hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams, PN_FS_WAVES_OUT, grid_cap)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
                      slot_r, hist, yring, eyring, last_period, Ps, feat, silence, aux);
 }
 
 // The three phase kernels in sequence = pn_launch_frontend (same arguments, same results bit for bit).
 void pn_launch_frontend_split(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
                               long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, float2 *Ps,
-                              float *feat, int *silence, int *last_period, float *last_gain, float *aux) {
-  pn_launch_fe_spec_in(st, T, n_streams, frame, in, in_is_i16, in_stride, i16_scale, hist, yring, eyring);
-  pn_launch_fe_pitch(st, n_streams, frame, hist, feat, last_period, last_gain, aux);
-  pn_launch_fe_spec_out(st, T, n_streams, frame, hist, yring, eyring, last_period, Ps, feat, silence, aux);
+                              float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap) {
+  pn_launch_fe_spec_in(st, T, n_streams, frame, in, in_is_i16, in_stride, i16_scale, hist, yring, eyring, grid_cap);
+  pn_launch_fe_pitch(st, n_streams, frame, hist, feat, last_period, last_gain, aux, grid_cap);
+  pn_launch_fe_spec_out(st, T, n_streams, frame, hist, yring, eyring, last_period, Ps, feat, silence, aux, grid_cap);
 }

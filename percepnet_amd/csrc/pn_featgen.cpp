@@ -74,8 +74,8 @@ extern "C" pn_featgen *pn_featgen_create(int device, int n_pairs, void *hip_stre
   {
     const size_t B = n_pairs;
     PnTables *ht = (PnTables *)malloc(sizeof(PnTables));
-    pn_build_tables(ht);
-    if (fg_alloc(c, (void **)&c->tables, sizeof(PnTables))) { free(ht); goto fail; }
+    if (!ht) { pn_set_error("out of host memory"); goto fail; }
+    if (pn_build_tables(ht) || fg_alloc(c, (void **)&c->tables, sizeof(PnTables))) { free(ht); goto fail; }
     hipError_t e = hipMemcpyAsync(c->tables, ht, sizeof(PnTables), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     free(ht);
@@ -126,15 +126,15 @@ static int fg_frame(pn_featgen *c, const int16_t *sp, const int16_t *no, long lo
   static const bool mono = getenv("PERCEPNET_FE") && (!strcmp(getenv("PERCEPNET_FE"), "mono") || !strcmp(getenv("PERCEPNET_FE"), "g4"));
   auto fe = mono ? pn_launch_frontend : pn_launch_frontend_split;
   fe(c->stream, c->tables, c->B, c->t, no, 1, in_stride, 1.f, c->noisy.hist, c->noisy.yring, c->noisy.eyring, c->noisy.Ps,
-     c->noisy.feat, c->noisy.silence, c->noisy.last_period, c->noisy.last_gain, c->noisy.aux);
+     c->noisy.feat, c->noisy.silence, c->noisy.last_period, c->noisy.last_gain, c->noisy.aux, 0);
   fe(c->stream, c->tables, c->B, c->t, sp, 1, in_stride, 1.f, c->clean.hist, c->clean.yring, c->clean.eyring, c->clean.Ps,
-     c->clean.feat, c->clean.silence, c->clean.last_period, c->clean.last_gain, c->clean.aux);
+     c->clean.feat, c->clean.silence, c->clean.last_period, c->clean.last_gain, c->clean.aux, 0);
   pn_launch_targets(c->stream, c->tables, c->B, c->clean.eyring + (size_t)slot_r * B * 36,
                     c->noisy.eyring + (size_t)slot_r * B * 36, c->noisy.eyring + (size_t)slot_w * B * 36, c->clean.aux,
                     c->noisy.aux, c->noisy.last_period, rec, rec_stride, c->gr);
   // the synthesis memory must advance every frame whether or not the caller keeps the PCM (753)
   pn_launch_backend(c->stream, c->tables, c->B, c->noisy.yring + (size_t)slot_r * B * PN_SPEC_BINS, c->noisy.Ps, c->gr,
-                    nullptr /* the targets kernel already post-filtered g (743) */, c->noisy.silence, c->synth, c->tmp_out, 0);
+                    nullptr /* the targets kernel already post-filtered g (743) */, c->noisy.silence, c->synth, c->tmp_out, 0, 0);
   if (pcm) pn_launch_saturate_i16(c->stream, c->B, c->tmp_out, pcm, pcm_stride);
   PN_HIP_CHECK(hipGetLastError());
   c->t++;

@@ -2,10 +2,10 @@
 #pragma once
 #include "pn_common.h"
 
-// Test hook of the create-time DSP self-test (pn_context.cpp: dsp_selftest): when > 0, every DSP launcher caps its grid
-// at this many blocks, so that a 40-stream batch walks several grid-stride rounds of ONE block (the regime in which a
-// mis-scheduled persistent loop once corrupted later rounds).  0 in normal operation.
-extern int g_pn_dsp_grid_cap;
+// grid_cap (last argument of every DSP launcher): test hook of the create-time DSP self-test (pn_context.cpp: dsp_selftest).
+// When > 0 the launcher caps its grid at this many blocks, so that a 40-stream batch walks several grid-stride rounds of ONE
+// block (the regime in which a mis-scheduled persistent loop once corrupted later rounds).  It is state of
+// the temporary self-test context only (pn_ctx::dsp_grid_cap): no other context, thread or device ever sees it.  0 = off.
 
 // ---- kernels / helpers implemented in pn_dsp.hip and pn_nn.hip -----------------------------------
 struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
@@ -13,25 +13,25 @@ struct PnSegs { const float *p[5]; int ld[5]; int width[5]; int n; };
 // denoise.cpp:41,697); aux: optional [n_streams][PN_AUX_STRIDE] side outputs for the training-feature path
 void pn_launch_frontend(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
                         int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
-                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+                        float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap);
 // the same kernel instantiated with two streams per wavefront (pn_dsp_fe_g2.hip): lower latency per stream, lower
 // throughput — used by small-batch contexts
 void pn_launch_frontend_g2(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in,
                            int in_is_i16, long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring,
-                           float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+                           float2 *Ps, float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap);
 // the phase-split front end (pn_dsp_fe_split_s.hip, pn_dsp_fe_split_p.hip): three launches with their own lane mapping
 // and register / LDS budget; spec_in and pitch are independent of each other, spec_out needs both.  Same results, bit
 // for bit, as pn_launch_frontend.
 void pn_launch_fe_spec_in(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
-                          long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring);
+                          long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, int grid_cap);
 void pn_launch_fe_pitch(hipStream_t st, int n_streams, int64_t frame, const float *hist, float *feat, int *last_period,
-                        float *last_gain, float *aux);
+                        float *last_gain, float *aux, int grid_cap);
 void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const float *hist,
                            const float2 *yring, const float *eyring, const int *last_period, float2 *Ps, float *feat,
-                           int *silence, float *aux);
+                           int *silence, float *aux, int grid_cap);
 void pn_launch_frontend_split(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
                               long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, float2 *Ps,
-                              float *feat, int *silence, int *last_period, float *last_gain, float *aux);
+                              float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,
@@ -39,7 +39,7 @@ void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const flo
 void pn_launch_saturate_i16(hipStream_t st, int n_pairs, const float *in, int16_t *out, long long out_stride);
 void pn_launch_backend(hipStream_t st, const PnTables *T, int n_streams, const float2 *Xs, const float2 *Ps,
                        const float *gr, const float *ex_postfilter /* NULL = off */, const int *silence, float *synth_mem,
-                       void *out, int out_is_i16);
+                       void *out, int out_is_i16, int grid_cap);
 size_t pn_packed_floats(int k_alloc, int ncols, int ct_round);
 void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp);
 int pn_dense_nt(int N);

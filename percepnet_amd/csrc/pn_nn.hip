@@ -217,10 +217,10 @@ __device__ __forceinline__ void pn_store_A1(float (*As)[LDT], const float4 &v, i
 #ifdef PN_NN_CLOCKS
 __device__ unsigned long long pn_nn_clk[4];
 __device__ unsigned long long pn_nn_trace[8192 * 4];     // per block of the last N=512 launch: start, end (100 MHz ticks), HW_ID, XCC_ID
-extern "C" int pn_nn_trace_read(unsigned long long *out) {
+extern "C" PN_EXPORT int pn_nn_trace_read(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_nn_trace), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -1;
 }
-extern "C" int pn_nn_clocks_read(unsigned long long *out, int reset) {
+extern "C" PN_EXPORT int pn_nn_clocks_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_nn_clk), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
   if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pn_nn_clk), z, sizeof(z)) != hipSuccess) return -1; }
   return 4;
@@ -542,37 +542,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
 #ifdef PN_NN_EXPERIMENTS
 #include "experimental/pn_nn_variants.inc"   // first-generation K loop and the wave-specialised variants (not built by default)
 #endif
-
-// ---- host: weight packing ---------------------------------------------------------------------
-// W[K][ncols] (reference layout) -> Wp[CT][ceil(K/32)][tile of 1024 floats], zero padded,
-// CT = ceil(ncols/32) rounded up to a multiple of ct_round (the kernel's column tiles per block).
-// A tile is stored in MFMA FRAGMENT order: element (column j, k_local = 8q + 2s + kh) at ((q*2 + kh)*32 + j)*4 + s, i.e.
-// eight 512-byte chunks (q, kh), each holding for the 32 columns the four k values one lane feeds to four consecutive
-// MFMA k-steps.  A wavefront whose lane = kh*32 + j reads chunk pair q with ONE fully coalesced 1 KB load (the
-// small-batch kernels take their B operand straight from global memory like that); the batch kernels stage a tile into
-// LDS with 256 linear float4 loads and un-permute while storing (pn_store_B).
-static inline int pn_ct_padded(int ncols, int ct_round) {
-  const int CT = (ncols + 31) / 32;
-  return ((CT + ct_round - 1) / ct_round) * ct_round;
-}
-// k_alloc >= K: number of K rows the kernel will sweep (the zero-padded panel width)
-size_t pn_packed_floats(int k_alloc, int ncols, int ct_round) {
-  return (size_t)pn_ct_padded(ncols, ct_round) * ((k_alloc + 31) / 32) * 1024;
-}
-void pn_pack_weights(const float *W, int K, int k_alloc, int ncols, int ct_round, float *Wp) {
-  const int CT = pn_ct_padded(ncols, ct_round), KT = (k_alloc + 31) / 32;
-  for (int ct = 0; ct < CT; ct++)
-    for (int kt = 0; kt < KT; kt++) {
-      float *tile = Wp + ((size_t)ct * KT + kt) * 1024;
-      for (int j = 0; j < 32; j++)
-        for (int kl = 0; kl < 32; kl++) {
-          const int q = kl >> 3, s = (kl & 7) >> 1, kh = kl & 1;
-          const int k = kt * 32 + kl, c = ct * 32 + j;
-          tile[((q * 2 + kh) * 32 + j) * 4 + s] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
-        }
-    }
-}
-int pn_dense_nt(int N) { return (N % 128 == 0) ? 4 : 2; }
 
 // ---- launchers -----------------------------------------------------------------------------------
 // Batches of at most this many streams run the small-batch kernel family (pn_nn_small.hip: one 32x32 tile and one

@@ -290,18 +290,6 @@ __global__ __launch_bounds__(64, 1) void pn_dense_n16_kernel(        // (64, 1):
   }
 }
 
-// weights of a narrow layer for pn_dense_n16_kernel: Wq[ct][t][lane][e] = W[k = 16t + 4e + (lane >> 4)][col = 16 ct + (lane & 15)]
-size_t pn_packed_floats_n16(int K, int ncols) { return (size_t)((ncols + 15) / 16) * ((K + 15) / 16) * 256; }
-void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq) {
-  const int CT = (ncols + 15) / 16, KG = (K + 15) / 16;
-  for (int ct = 0; ct < CT; ct++)
-    for (int t = 0; t < KG; t++)
-      for (int lane = 0; lane < 64; lane++)
-        for (int e = 0; e < 4; e++) {
-          const int k = 16 * t + 4 * e + (lane >> 4), c = 16 * ct + (lane & 15);
-          Wq[(((size_t)ct * KG + t) * 64 + lane) * 4 + e] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
-        }
-}
 void pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
                          const float *tansig, float *out, int ldo, int n_rows) {
   const int gps = A.width[0] / 16, KG = gps * A.n;      // equal-width panels, widths multiples of 16 (128, 512)

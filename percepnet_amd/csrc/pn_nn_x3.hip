@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_dense_x3_kernel(
 // Tuning aid (-DPN_X3_CLOCKS): shader-clock stamps of wave 0 of every block of the last N=512 launch
 #ifdef PN_X3_CLOCKS
 __device__ unsigned long long pn_x3_trace[4096 * 8];
-extern "C" int pn_x3_trace_read(unsigned long long *out) {
+extern "C" PN_EXPORT int pn_x3_trace_read(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3_trace), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
 }
 #define X3_STAMP(i) do { if (N == 512) ck_[i] = __builtin_readcyclecounter(); } while (0)
@@ -473,10 +473,10 @@ __device__ __forceinline__ void x3_pin(int &v) { asm volatile("" : "+v"(v)); }
 #ifdef PN_X3_CLOCKS
 __device__ unsigned long long pn_x3p_trace[256 * 2 * 8];
 __device__ unsigned pn_x3p_hwid[256 * 8];              // HW_ID of every wave of every block of the last N = 512 launch
-extern "C" int pn_x3p_trace_read(unsigned long long *out) {
+extern "C" PN_EXPORT int pn_x3p_trace_read(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3p_trace), sizeof(unsigned long long) * 256 * 2 * 8) == hipSuccess ? 0 : -1;
 }
-extern "C" int pn_x3p_hwid_read(unsigned *out) {
+extern "C" PN_EXPORT int pn_x3p_hwid_read(unsigned *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pn_x3p_hwid), sizeof(unsigned) * 256 * 8) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -20,7 +20,7 @@
 static float pn_freq2erb(float freq_hz) { return 9.265 * log(1 + freq_hz / (24.7 * 9.265)); }
 static float pn_erb2freq(float n_erb) { return 24.7 * 9.265 * (exp(n_erb / 9.265) - 1); }
 
-void pn_build_tables(PnTables *t) {
+int pn_build_tables(PnTables *t) {
   memset(t, 0, sizeof(*t));
   for (int i = 0; i < PN_NFFT; i++) {
     const double pi = 3.14159265358979323846264338327;
@@ -84,9 +84,9 @@ void pn_build_tables(PnTables *t) {
       t->band_nq[b] = (uint16_t)((pos - t->band_start[b]) / 4);
     }
     if (pos != PN_BAND_LAYOUT_FLOATS || border[PN_NB - 1] != PN_SPEC_BINS) {
-      fprintf(stderr, "percepnet_hip: band layout is %d floats / last border %d, the kernels are built for %d / %d\n", pos,
-              border[PN_NB - 1], PN_BAND_LAYOUT_FLOATS, PN_SPEC_BINS);
-      abort();
+      pn_set_error("band layout is %d floats / last border %d, the kernels are built for %d / %d (pn_tables.cpp and the "
+                   "DSP kernels disagree: rebuild)", pos, border[PN_NB - 1], PN_BAND_LAYOUT_FLOATS, PN_SPEC_BINS);
+      return -1;
     }
   }
   for (int i = 0; i <= 200; i++) {
@@ -95,4 +95,5 @@ void pn_build_tables(PnTables *t) {
     snprintf(buf, sizeof(buf), "%f", (double)v);
     t->tansig[i] = (float)strtod(buf, NULL);
   }
+  return 0;
 }

@@ -8,7 +8,10 @@
 //
 // One DenoiseState = a batch-of-one context.  That is correct but launch-bound (13 kernel
 // launches and two PCIe hops per 10 ms frame); throughput lives in the batched pn_* API.
+#include "pn_common.h"
 #include "../../include/percepnet_hip.h"
+// the reference's own (C++-mangled) entry points: exported like the C-ABI (the library is built with -fvisibility=hidden)
+#define PN_REF_EXPORT __attribute__((visibility("default")))
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -27,7 +30,7 @@ struct DenoiseState {
 };
 #define DS_MAGIC 0x504e4453u
 
-int rnnoise_get_size() { return (int)sizeof(DenoiseState); }
+PN_REF_EXPORT int rnnoise_get_size() { return (int)sizeof(DenoiseState); }
 
 // rnnoise_init (denoise.cpp:259-280): zero state, bind the model.  Returns 0; on failure the
 // state is left inert (process_frame then outputs silence) and pn_last_error() says why —
@@ -43,7 +46,7 @@ static int env_mode() {
   return (x && atoi(x)) ? PN_NN_MFMA_X3 : PN_NN_MFMA;
 }
 
-int rnnoise_init(DenoiseState *st, RNNModel *model) {
+PN_REF_EXPORT int rnnoise_init(DenoiseState *st, RNNModel *model) {
   memset(st, 0, sizeof(*st));
   st->magic = DS_MAGIC;
   const RNNModel *m = model ? model : (&percepnet_model_orig ? &percepnet_model_orig : NULL);
@@ -66,13 +69,13 @@ int rnnoise_init(DenoiseState *st, RNNModel *model) {
   return 0;
 }
 
-DenoiseState *rnnoise_create(RNNModel *model) {
+PN_REF_EXPORT DenoiseState *rnnoise_create(RNNModel *model) {
   DenoiseState *st = (DenoiseState *)malloc(rnnoise_get_size());
   if (st) rnnoise_init(st, model);
   return st;
 }
 
-void rnnoise_destroy(DenoiseState *st) {
+PN_REF_EXPORT void rnnoise_destroy(DenoiseState *st) {
   if (!st) return;
   if (st->magic == DS_MAGIC) { pn_ctx_destroy(st->ctx); pn_model_free(st->model); }
   free(st);
@@ -81,7 +84,7 @@ void rnnoise_destroy(DenoiseState *st) {
 // rnnoise_process_frame (denoise.cpp:508-547): 480 floats in -> 480 floats out (may alias), the
 // 68-float g|r tap appended to f_feature (the reference requires it non-NULL; NULL is accepted
 // here).  Always returns 0 like the reference.
-float rnnoise_process_frame(DenoiseState *st, float *out, const float *in, FILE *f_feature) {
+PN_REF_EXPORT float rnnoise_process_frame(DenoiseState *st, float *out, const float *in, FILE *f_feature) {
   if (!st || st->magic != DS_MAGIC || !st->ctx) { if (out) memset(out, 0, PN_FRAME_SIZE * sizeof(float)); return 0; }
   float tmp[PN_FRAME_SIZE];
   memcpy(tmp, in, sizeof(tmp));
@@ -113,7 +116,7 @@ static void rnn_cache_drop(const RNNModel *key) {          // caller holds g_rnn
   g_rnn_ctx.erase(it);
 }
 
-void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *input) {
+PN_REF_EXPORT void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *input) {
   if (!rnn || !rnn->model || !gains || !strengths || !input) return;
   std::lock_guard<std::mutex> lk(g_rnn_mu);
   auto it = g_rnn_ctx.find(rnn->model);
@@ -142,50 +145,45 @@ void compute_rnn(RNNState *rnn, float *gains, float *strengths, const float *inp
   memcpy(gains, gr, 34 * sizeof(float)); memcpy(strengths, gr + 34, 34 * sizeof(float));
 }
 
-// rnnoise_model_from_file / rnnoise_model_free are declared by the reference (rnnoise.h:62-64)
-// but defined nowhere; here they read/free a PNW1 container materialised as nnet_data.h records.
-struct OwnedModel { RNNModel m; DenseLayer d[3]; Conv1DLayer c[2]; GRULayer g[5]; float *data; };
+// rnnoise_model_from_file / rnnoise_model_free are declared by the reference (rnnoise.h:62-64) but defined nowhere; here
+// they read / free a PNW1 container materialised as nnet_data.h records.  One parser: the container is validated by
+// pn_model_from_file (fixed topology checked before any size is used), the records point into that model's storage.
+// rnnoise_model_free only frees what rnnoise_model_from_file returned (a registry, not a guess about the memory in front
+// of the pointer): a foreign RNNModel — the link-time percepnet_model_orig, a caller's own struct — is left alone.
+struct OwnedModel { RNNModel m; DenseLayer d[3]; Conv1DLayer c[2]; GRULayer g[5]; pn_model *pm; };
+static std::mutex g_owned_mu;
+static std::map<const RNNModel *, OwnedModel *> g_owned;
 
-RNNModel *rnnoise_model_from_file(FILE *f) {
-  if (!f) return NULL;
-  size_t cap = 1 << 20, n = 0;
-  unsigned char *buf = (unsigned char *)malloc(cap);
-  for (;;) {
-    size_t r = fread(buf + n, 1, cap - n, f);
-    n += r;
-    if (r == 0) break;
-    if (n == cap) { cap *= 2; buf = (unsigned char *)realloc(buf, cap); }
-  }
-  if (n < 8 || memcmp(buf, "PNW1", 4) != 0) { free(buf); return NULL; }
+PN_REF_EXPORT RNNModel *rnnoise_model_from_file(FILE *f) {
+  pn_model *pm = pn_model_from_file(f);
+  if (!pm) return NULL;
   OwnedModel *o = (OwnedModel *)calloc(1, sizeof(OwnedModel));
-  o->data = (float *)malloc(n);
-  size_t off = 8, fo = 0; int nd = 0, nc = 0, ng = 0; bool ok = true;
-  for (int li = 0; li < 10 && ok; li++) {
-    uint32_t h[6];
-    if (off + 24 > n) { ok = false; break; }
-    memcpy(h, buf + off, 24); off += 24;
-    const size_t nb = h[0] == 2 ? 6 * (size_t)h[2] : h[2];
-    const size_t nw = (size_t)h[1] * h[3] * h[2] * (h[0] == 2 ? 3 : 1);
-    const size_t nr = h[0] == 2 ? (size_t)h[2] * 3 * h[2] : 0;
-    if (off + 4 * (nb + nw + nr) > n) { ok = false; break; }
-    memcpy(o->data + fo, buf + off, 4 * (nb + nw + nr)); off += 4 * (nb + nw + nr);
-    const float *b = o->data + fo, *w = b + nb, *rw = w + nw; fo += nb + nw + nr;
-    if (h[0] == 0 && nd < 3) o->d[nd++] = {b, w, (int)h[1], (int)h[2], (int)h[4]};
-    else if (h[0] == 1 && nc < 2) o->c[nc++] = {b, w, (int)h[1], (int)h[3], (int)h[2], (int)h[4]};
-    else if (h[0] == 2 && ng < 5) o->g[ng++] = {b, w, rw, (int)h[1], (int)h[2], (int)h[4], (int)h[5]};
-    else ok = false;
-  }
-  free(buf);
-  if (!ok || nd != 3 || nc != 2 || ng != 5) { free(o->data); free(o); return NULL; }
+  if (!o) { pn_model_free(pm); return NULL; }
+  o->pm = pm;
+  const PnLayerHost *L = pm->L;
+  const int di[3] = {PN_L_FC, PN_L_FC_GB, PN_L_FC_RB};
+  for (int i = 0; i < 3; i++) { const PnLayerHost &H = L[di[i]]; o->d[i] = {H.bias, H.w, H.nin, H.nn, H.act}; }
+  for (int i = 0; i < 2; i++) { const PnLayerHost &H = L[PN_L_CONV1 + i]; o->c[i] = {H.bias, H.w, H.nin, H.ks, H.nn, H.act}; }
+  for (int i = 0; i < 5; i++) { const PnLayerHost &H = L[PN_L_GRU1 + i]; o->g[i] = {H.bias, H.w, H.rw, H.nin, H.nn, H.act, H.reset_after}; }
   o->m = {&o->d[0], &o->c[0], &o->c[1], &o->g[0], &o->g[1], &o->g[2], &o->g[3], &o->g[4], &o->d[1], &o->d[2]};
-  return &o->m;   // RNNModel is the first member: the same address frees the whole record
+  std::lock_guard<std::mutex> lk(g_owned_mu);
+  g_owned[&o->m] = o;
+  return &o->m;
 }
 
-void rnnoise_model_free(RNNModel *model) {
+PN_REF_EXPORT void rnnoise_model_free(RNNModel *model) {
   if (!model) return;
+  OwnedModel *o = NULL;
+  {
+    std::lock_guard<std::mutex> lk(g_owned_mu);
+    auto it = g_owned.find(model);
+    if (it == g_owned.end()) return;                       // not ours: nothing to free, nothing to corrupt
+    o = it->second;
+    g_owned.erase(it);
+  }
   { std::lock_guard<std::mutex> lk(g_rnn_mu); rnn_cache_drop(model); }   // a later model at this address starts clean
-  OwnedModel *o = (OwnedModel *)model;
-  free(o->data); free(o);
+  pn_model_free(o->pm);
+  free(o);
 }
 
 extern "C" {
@@ -203,7 +201,7 @@ void rnnoise_compute_rnn_c(RNNState *rnn, float *gains, float *strengths, const 
 // Same argv contract (<speech> <noisy> <count> <output>) and the same by-products in the cwd
 // (test_output.pcm, test_input.pcm); one job = a batch of one pair — for dataset-scale runs use
 // pn_featgen_run_files / the percepnet_featgen CLI with many jobs per call.
-int train(int argc, char **argv) {
+PN_REF_EXPORT int train(int argc, char **argv) {
   if (argc != 5) {
     fprintf(stderr, "usage: %s <speech> <noisy> <count> <output>\n", argv[0]);
     return 1;
