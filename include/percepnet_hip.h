@@ -75,6 +75,13 @@ void pn_model_free(pn_model *m);
 pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream);
 void pn_ctx_destroy(pn_ctx *ctx);
 int pn_ctx_reset(pn_ctx *ctx);                       /* zero all stream state, frame counter = 0 */
+/* Per-stream lifecycle: put the n streams ids[0..n) (host array, each in [0, n_streams), duplicates allowed) back into
+   the state rnnoise_init leaves ONE DenoiseState in (denoise.cpp:259-280: all-zero DSP and network state) while every
+   other stream of the context keeps its state and the context keeps its frame counter — the batched counterpart of
+   rnnoise_destroy + rnnoise_create for a slot whose call has ended and whose next call begins.  Asynchronous on the
+   context's stream: it takes effect between the frames submitted before and after it (also on the pipelined host path).
+   The first frame processed after it is that stream's frame 0 (its first output frame is the one main.cpp:37 skips). */
+int pn_ctx_reset_streams(pn_ctx *ctx, const int32_t *ids, int n);
 int pn_ctx_n_streams(const pn_ctx *ctx);
 int64_t pn_ctx_frames_done(const pn_ctx *ctx);
 size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state + weights */

@@ -48,6 +48,7 @@ def load_library():
     L.pn_ctx_create.argtypes = [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]
     L.pn_ctx_destroy.argtypes = [_vp]
     L.pn_ctx_reset.argtypes = [_vp]
+    L.pn_ctx_reset_streams.argtypes = [_vp, _vp, ctypes.c_int]
     L.pn_ctx_n_streams.argtypes = [_vp]
     L.pn_ctx_frames_done.restype = ctypes.c_int64
     L.pn_ctx_frames_done.argtypes = [_vp]
@@ -145,6 +146,11 @@ class Context:
 
     def reset(self):
         self._chk(self.L.pn_ctx_reset(self.h))
+
+    def reset_streams(self, ids):
+        """rnnoise_init for the streams `ids` only (the others keep running): include/percepnet_hip.h pn_ctx_reset_streams."""
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).ravel())
+        self._chk(self.L.pn_ctx_reset_streams(self.h, a.ctypes.data, int(a.size)))
 
     def synchronize(self):
         self._chk(self.L.pn_ctx_synchronize(self.h))

@@ -64,6 +64,7 @@ struct pn_model {
   PnLayerHost L[PN_NLAYERS];
   float *storage;               // one malloc holding every array
   size_t n_floats;
+  uint64_t content_hash;        // of the arrays and the layer descriptors: key of the per-device cache of packed weights
 };
 
 #ifndef PN_NO_HIP

@@ -28,6 +28,20 @@ enum { FE_MONO_G4 = 0, FE_MONO_G2 = 1, FE_SPLIT = 2 };
 
 struct DevLayer { float *bias, *w, *rw, *wp, *rwp, *wq; };   // wq: narrow layers of small-batch fp32 contexts (pn_pack_weights_n16)
 
+// Device copy of a model's biases and (re-packed) weights, shared by every context of one (model content, device, network
+// mode, narrow-layer packing): the reference binds all its states to ONE static model (denoise.cpp:49-51,267: a borrowed
+// pointer, zero copies); here N contexts — N legacy rnnoise_create handles, the shards of a CLI run, a service that opens
+// and closes contexts — share one 32 MB upload and one re-pack instead of N.  Reference-counted, freed with its last user.
+struct SharedWeights {
+  int refs = 0;
+  DevLayer L[PN_NLAYERS];
+  std::vector<void *> allocs;
+  size_t bytes = 0;
+};
+typedef std::tuple<uint64_t, int, int, int> WeightsKey;      // content hash, device, nn_mode, narrow layers packed for the n16 kernel
+static std::mutex g_weights_mu;
+static std::map<WeightsKey, SharedWeights *> g_weights;
+
 struct pn_ctx {
   int device, B, nn_mode;
   int x3_rg;                       // split-precision mode: row groups of 32 per wave (1: 128-row blocks, 2: 256-row blocks), fixed at creation from B
@@ -42,7 +56,9 @@ struct pn_ctx {
                                    // callable on an RNNState without a DenoiseState in the reference too)
   size_t bytes;
   PnLayerHost geom[PN_NLAYERS];
-  DevLayer L[PN_NLAYERS];
+  DevLayer L[PN_NLAYERS];           // = weights->L (pointers into the shared copy)
+  SharedWeights *weights = NULL; WeightsKey weights_key; bool weights_were_cached = false;
+  int *d_ids = NULL; int ids_cap = 0;    // pn_ctx_reset_streams: stream ids on the device
   PnTables *tables; float *tansig;
   float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
   // fp16-operand variant only: shadow copies (2 bytes per element, same indexing) of the buffers the GEMMs read
@@ -70,7 +86,7 @@ struct pn_ctx {
 };
 
 static thread_local bool g_last_alloc_oom = false;     // the last dev_alloc failure on this thread was hipErrorOutOfMemory
-static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
+static int dev_alloc_into(std::vector<void *> &allocs, size_t &total, hipStream_t stream, void **p, size_t bytes, bool zero) {
   // PERCEPNET_GUARD=1 (debugging aid): every buffer is followed by 1 MB of 0xFF (NaN as fp32 and as fp16), so that a
   // read past the end of a buffer shows up as NaN in the outputs instead of as run-to-run noise
   static const bool guard = getenv("PERCEPNET_GUARD") != NULL;
@@ -84,17 +100,24 @@ static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) {
       return -1;
     }
   }
-  c->allocs.push_back(*p);
-  c->bytes += bytes;
-  if (zero) PN_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, c->stream));
-  if (guard) PN_HIP_CHECK(hipMemsetAsync((char *)*p + body, 0xFF, pad, c->stream));
+  allocs.push_back(*p);
+  total += bytes;
+  if (zero) PN_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, stream));
+  if (guard) PN_HIP_CHECK(hipMemsetAsync((char *)*p + body, 0xFF, pad, stream));
   return 0;
 }
+static int dev_alloc(pn_ctx *c, void **p, size_t bytes, bool zero) { return dev_alloc_into(c->allocs, c->bytes, c->stream, p, bytes, zero); }
 #define DEV_ALLOC(ptr, count, zero) \
   do { if (dev_alloc(c, (void **)&(ptr), sizeof(*(ptr)) * (size_t)(count), zero)) goto fail; } while (0)
 
 static int upload(pn_ctx *c, float **dst, const float *src, size_t n) {
   if (dev_alloc(c, (void **)dst, n * sizeof(float), false)) return -1;
+  PN_HIP_CHECK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+// the same into the shared weight copy under construction (uploads run on the creating context's stream)
+static int upload_w(pn_ctx *c, SharedWeights *w, float **dst, const float *src, size_t n) {
+  if (dev_alloc_into(w->allocs, w->bytes, c->stream, (void **)dst, n * sizeof(float), false)) return -1;
   PN_HIP_CHECK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   return 0;
 }
@@ -167,12 +190,79 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
   for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void *p : c->allocs) hipFree(p);
+  if (c->weights) {
+    std::lock_guard<std::mutex> lk(g_weights_mu);
+    if (--c->weights->refs == 0) {
+      for (void *p : c->weights->allocs) hipFree(p);
+      g_weights.erase(c->weights_key);
+      delete c->weights;
+    }
+  }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
 
 extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream) {
   return ctx_create(model, device, n_streams, nn_mode, hip_stream, true, -1, -1);
+}
+
+// Biases + weights of `model` on the context's device in the layout `nn_mode` reads: STRICT the nnet_data.h arrays as they
+// are, the MFMA modes re-packed tile orders (pn_pack.cpp, pn_nn_x3.hip).  Returns NULL (pn_set_error) on failure.
+static SharedWeights *build_weights(pn_ctx *c, const pn_model *model, int nn_mode, bool n16) {
+  SharedWeights *w = new SharedWeights();
+  memset(w->L, 0, sizeof(w->L));
+  for (int li = 0; li < PN_NLAYERS; li++) {
+    const PnLayerHost &H = model->L[li];
+    size_t nb, nw, nr;
+    pn_layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
+    if (upload_w(c, w, &w->L[li].bias, H.bias, nb)) goto fail_w;
+    if (nn_mode == PN_NN_STRICT) {
+      if (upload_w(c, w, &w->L[li].w, H.w, nw)) goto fail_w;
+      if (nr && upload_w(c, w, &w->L[li].rw, H.rw, nr)) goto fail_w;
+    } else {
+      const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
+      const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
+      const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
+      if ((nn_mode == PN_NN_MFMA_X3 || nn_mode == PN_NN_MFMA_F16) && x3_layer(li)) {   // conv1, conv2, the GRUs and fc_gb; fc and fc_rb (K = 70 / 128) stay fp32 below
+        const int np = nn_mode == PN_NN_MFMA_X3 ? 2 : 1;         // operand planes: hi + lo (split precision) or hi only (fp16 operands)
+        const int ctx3 = H.kind == PN_KIND_GRU ? 1 : pn_dense_x3_nt(H.nn);
+        std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3, np));
+        if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, np, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the fp16-operand and split-precision modes cannot represent it", li); goto fail_w; }
+        if (upload_w(c, w, &w->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail_w;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;   // `packed` dies at scope end
+        if (nr) {
+          std::vector<uint16_t> rp(pn_packed_halfs_x3(H.nn, ncols, 1, np));
+          if (pn_pack_weights_x3(H.rw, H.nn, H.nn, ncols, 1, np, rp.data())) { pn_set_error("layer %d has a recurrent weight outside the fp16 range", li); goto fail_w; }
+          if (upload_w(c, w, &w->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail_w;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;
+        }
+      } else {
+        std::vector<float> packed(pn_packed_floats(k_alloc, ncols, ctr));
+        pn_pack_weights(H.w, K, k_alloc, ncols, ctr, packed.data());
+        if (upload_w(c, w, &w->L[li].wp, packed.data(), packed.size())) goto fail_w;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;   // `packed` dies at scope end
+        if (n16 && H.kind == PN_KIND_DENSE && ncols <= 48 && K % 128 == 0) {     // fc_gb, fc_rb
+          std::vector<float> pq(pn_packed_floats_n16(K, ncols));
+          pn_pack_weights_n16(H.w, K, ncols, pq.data());
+          if (upload_w(c, w, &w->L[li].wq, pq.data(), pq.size())) goto fail_w;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;
+        }
+        if (nr) {
+          std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
+          pn_pack_weights(H.rw, H.nn, H.nn, ncols, 1, rp.data());
+          if (upload_w(c, w, &w->L[li].rwp, rp.data(), rp.size())) goto fail_w;
+          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;
+        }
+      }
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("weight upload failed"); goto fail_w; }
+  return w;
+fail_w:
+  hipStreamSynchronize(c->stream);
+  for (void *p : w->allocs) hipFree(p);
+  delete w;
+  return NULL;
 }
 
 // force_small / force_small_gru: -1 = choose the network kernel family from the batch size (the public behaviour);
@@ -238,51 +328,20 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   DEV_ALLOC(c->io_in, B * PN_FRAME, false);
   DEV_ALLOC(c->io_out, B * PN_FRAME, false);
   if (zero_state(c)) goto fail;
-  for (int li = 0; li < PN_NLAYERS; li++) {
-    const PnLayerHost &H = model->L[li];
-    c->geom[li] = H; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL;
-    size_t nb, nw, nr;
-    pn_layer_floats(H.kind, H.nin, H.nn, H.ks, &nb, &nw, &nr);
-    if (upload(c, &c->L[li].bias, H.bias, nb)) goto fail;
-    if (nn_mode == PN_NN_STRICT) {
-      if (upload(c, &c->L[li].w, H.w, nw)) goto fail;
-      if (nr && upload(c, &c->L[li].rw, H.rw, nr)) goto fail;
-    } else {
-      const int K = H.nin * H.ks, ncols = H.nn * (H.kind == PN_KIND_GRU ? 3 : 1);
-      const int k_alloc = (li == PN_L_FC) ? PN_FEAT_STRIDE : K;   // fc sweeps the zero-padded feature panel
-      const int ctr = H.kind == PN_KIND_GRU ? 1 : pn_dense_nt(H.nn);
-      if ((nn_mode == PN_NN_MFMA_X3 || nn_mode == PN_NN_MFMA_F16) && x3_layer(li)) {   // conv1, conv2, the GRUs and fc_gb; fc and fc_rb (K = 70 / 128) stay fp32 below
-        const int np = nn_mode == PN_NN_MFMA_X3 ? 2 : 1;         // operand planes: hi + lo (split precision) or hi only (fp16 operands)
-        const int ctx3 = H.kind == PN_KIND_GRU ? 1 : pn_dense_x3_nt(H.nn);
-        std::vector<uint16_t> packed(pn_packed_halfs_x3(K, ncols, ctx3, np));
-        if (pn_pack_weights_x3(H.w, K, K, ncols, ctx3, np, packed.data())) { pn_set_error("layer %d has a weight outside the fp16 range: the fp16-operand and split-precision modes cannot represent it", li); goto fail; }
-        if (upload(c, &c->L[li].wp, (const float *)packed.data(), packed.size() / 2)) goto fail;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
-        if (nr) {
-          std::vector<uint16_t> rp(pn_packed_halfs_x3(H.nn, ncols, 1, np));
-          if (pn_pack_weights_x3(H.rw, H.nn, H.nn, ncols, 1, np, rp.data())) { pn_set_error("layer %d has a recurrent weight outside the fp16 range", li); goto fail; }
-          if (upload(c, &c->L[li].rwp, (const float *)rp.data(), rp.size() / 2)) goto fail;
-          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
-        }
-      } else {
-        std::vector<float> packed(pn_packed_floats(k_alloc, ncols, ctr));
-        pn_pack_weights(H.w, K, k_alloc, ncols, ctr, packed.data());
-        if (upload(c, &c->L[li].wp, packed.data(), packed.size())) goto fail;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;   // `packed` dies at scope end
-        if (n16_rows_ok(n_streams) && H.kind == PN_KIND_DENSE && ncols <= 48 && K % 128 == 0) {     // fc_gb, fc_rb
-          std::vector<float> pq(pn_packed_floats_n16(K, ncols));
-          pn_pack_weights_n16(H.w, K, ncols, pq.data());
-          if (upload(c, &c->L[li].wq, pq.data(), pq.size())) goto fail;
-          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
-        }
-        if (nr) {
-          std::vector<float> rp(pn_packed_floats(H.nn, ncols, 1));
-          pn_pack_weights(H.rw, H.nn, H.nn, ncols, 1, rp.data());
-          if (upload(c, &c->L[li].rwp, rp.data(), rp.size())) goto fail;
-          if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail;
-        }
-      }
+  for (int li = 0; li < PN_NLAYERS; li++) { c->geom[li] = model->L[li]; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL; }
+  {   // the device copy of the weights: shared with every other context of this model content on this device in this mode
+    const bool n16 = (nn_mode == PN_NN_MFMA) && n16_rows_ok(n_streams);
+    c->weights_key = std::make_tuple(model->content_hash, device, nn_mode, n16 ? 1 : 0);
+    std::lock_guard<std::mutex> lk(g_weights_mu);
+    auto it = g_weights.find(c->weights_key);
+    if (it != g_weights.end()) { c->weights = it->second; c->weights_were_cached = true; }
+    else {
+      c->weights = build_weights(c, model, nn_mode, n16);
+      if (!c->weights) goto fail;
+      g_weights[c->weights_key] = c->weights;
     }
+    c->weights->refs++;
+    memcpy(c->L, c->weights->L, sizeof(c->L));
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
   if (selftest && nn_mode != PN_NN_STRICT && nn_selftest(c)) goto fail;
@@ -295,9 +354,56 @@ fail:
 
 static int pipe_drain(pn_ctx *c);
 extern "C" int pn_ctx_reset(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); if (pipe_drain(c)) return -1; return zero_state(c); }
+// rnnoise_init for a subset of the streams (denoise.cpp:259-280): every row of stream s in every ring slot / ping-pong half
+// of every state buffer goes to zero (pn_state.hip says why that is a fresh stream whatever the ring phases are)
+extern "C" int pn_ctx_reset_streams(pn_ctx *c, const int32_t *ids, int n) {
+  if (!c || n < 0 || (n > 0 && !ids)) { pn_set_error("bad argument"); return -1; }
+  if (n == 0) return 0;
+  for (int i = 0; i < n; i++) if (ids[i] < 0 || ids[i] >= c->B) { pn_set_error("stream id %d out of range [0, %d)", ids[i], c->B); return -1; }
+  PN_ON_DEVICE(c);
+  if (c->ids_cap < n) {
+    int cap = n < 1024 ? 1024 : n; if (cap > c->B) cap = c->B > n ? c->B : n;
+    int *p = NULL;
+    PN_HIP_CHECK(hipMalloc((void **)&p, (size_t)cap * sizeof(int)));      // (the old, smaller buffer stays in allocs until destroy:
+    c->allocs.push_back(p); c->d_ids = p; c->ids_cap = cap;                // kernels of an earlier call may still be reading it)
+  }
+  // a pageable source is staged before hipMemcpyAsync returns: the caller's array is free again, and the copy is ordered
+  // on the context's stream behind the frames already submitted and the previous call's kernels
+  std::vector<int32_t> tmp(ids, ids + n);
+  PN_HIP_CHECK(hipMemcpyAsync(c->d_ids, tmp.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipStream_t st = c->stream; const int *d = c->d_ids;
+  const long long B = c->B, Bp = (long long)c->Bp;
+  pn_launch_zero_rows(st, c->hist, PN_HIST_STRIDE, PN_HIST_STRIDE, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->synth, PN_FRAME, PN_FRAME, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->yring, 2 * PN_SPEC_BINS, 2 * PN_SPEC_BINS, 6, B * 2 * PN_SPEC_BINS, d, n);
+  pn_launch_zero_rows(st, c->eyring, 36, 36, 6, B * 36, d, n);
+  pn_launch_zero_rows(st, c->Ps, 2 * PN_SPEC_BINS, 2 * PN_SPEC_BINS, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->last_gain, 1, 1, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->last_period, 1, 1, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->silence, 1, 1, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->feat, PN_FEAT_STRIDE, PN_FEAT_STRIDE, 1, 0, d, n);
+  pn_launch_zero_rows(st, c->c1ring, 128, 128, 5, Bp * 128, d, n);
+  pn_launch_zero_rows(st, c->c2ring, 512, 512, 3, Bp * 512, d, n);
+  pn_launch_zero_rows(st, c->c2out, 512, 512, 1, 0, d, n);
+  for (int i = 0; i < 4; i++) pn_launch_zero_rows(st, c->gru[i], 512, 512, 2, Bp * 512, d, n);
+  pn_launch_zero_rows(st, c->rb, 128, 128, 2, Bp * 128, d, n);
+  pn_launch_zero_rows(st, c->gr, 68, 68, 1, 0, d, n);
+  if (c->c1ringH) {                                        // operand shadows of the fp16-operand / split-precision modes
+    const int np = (int)shadow_halfs_per_element(c);
+    pn_launch_zero_shadow_rows(st, c->c1ringH, 128, np, 5, np * Bp * 128, d, n);
+    pn_launch_zero_shadow_rows(st, c->c2ringH, 512, np, 3, np * Bp * 512, d, n);
+    pn_launch_zero_shadow_rows(st, c->c2outH, 512, np, 1, 0, d, n);
+    for (int i = 0; i < 4; i++) pn_launch_zero_shadow_rows(st, c->gruH[i], 512, np, 2, np * Bp * 512, d, n);
+    pn_launch_zero_shadow_rows(st, c->rbH, 128, np, 2, np * Bp * 128, d, n);
+  }
+  PN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 extern "C" int pn_ctx_n_streams(const pn_ctx *c) { return c ? c->B : -1; }
 extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
-extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes : 0; }
+// state (+ tables) of this context, plus the weights if this context created their device copy (a context that found them
+// in the cache adds nothing: the copy is shared)
+extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes + ((c->weights && !c->weights_were_cached) ? c->weights->bytes : 0) : 0; }
 extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
@@ -306,9 +412,10 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   // rows per wave (conv1, conv2, GRUs, fc_gb); x3_rg 3 = 64 rows with the GRUs on the paired-phase kernel (pn_gru_x3p_kernel)
   const char *xk = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg >= 2 ? "x3_rows64" : "x3_rows32") : (c->x3_rg >= 2 ? "f16_rows64" : "f16_rows32");
   const char *xg = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 3 ? "x3_rows64_paired" : xk) : (c->x3_rg == 3 ? "f16_rows64_paired" : xk);
-  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
+  const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s weights=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
                          x3 ? xg : (fam && c->small_gru ? "small" : "batch"), x3 ? xg : (fam && c->small ? "small" : "batch"),
-                         c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"));
+                         c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
+                         c->weights_were_cached ? "shared" : "own");
   return (w < 0 || (size_t)w >= n) ? -1 : w;
 }
 extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }

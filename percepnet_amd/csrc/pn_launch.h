@@ -32,6 +32,11 @@ void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int
 void pn_launch_frontend_split(hipStream_t st, const PnTables *T, int n_streams, int64_t frame, const void *in, int in_is_i16,
                               long long in_stride, float i16_scale, float *hist, float2 *yring, float *eyring, float2 *Ps,
                               float *feat, int *silence, int *last_period, float *last_gain, float *aux, int grid_cap);
+// per-stream re-initialisation (pn_state.hip): rows ids[] of a [n_slots][rows][row_floats] array / of a fragment-order shadow
+void pn_launch_zero_rows(hipStream_t st, void *base, int row_floats, long long row_stride, int n_slots, long long slot_stride,
+                         const int *d_ids, int n);
+void pn_launch_zero_shadow_rows(hipStream_t st, void *S, int width, int np, int n_slots, long long slot_stride_halfs,
+                                const int *d_ids, int n);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,

@@ -64,6 +64,14 @@ pn_model *pn_model_from_sources(const PnLayerSrc *src) {
     memcpy(p, src[li].w, nw * 4); L.w = p; p += nw;
     if (nr) { memcpy(p, src[li].rw, nr * 4); L.rw = p; p += nr; } else L.rw = NULL;
   }
+  // content hash (64-bit multiply-xorshift over 8-byte words; the arrays are 4-byte floats, n_floats is even or the last
+  // word is taken alone): two models with the same weights and activations share one packed copy per device and mode
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  auto mix = [&](uint64_t v) { h ^= v; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; };
+  for (size_t i = 0; i + 1 < total; i += 2) { uint64_t v; memcpy(&v, m->storage + i, 8); mix(v); }
+  if (total & 1) { uint32_t v; memcpy(&v, m->storage + total - 1, 4); mix(v); }
+  for (int li = 0; li < PN_NLAYERS; li++) mix(((uint64_t)(uint32_t)m->L[li].act << 32) | (uint32_t)m->L[li].reset_after);
+  m->content_hash = h;
   return m;
 }
 

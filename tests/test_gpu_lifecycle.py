@@ -1,0 +1,143 @@
+"""Per-stream lifecycle and shared weights of the batched C-ABI (-m gpu; round-3 verdict item 4).
+
+The reference's unit is ONE stream: rnnoise_create / rnnoise_init zero one DenoiseState, rnnoise_destroy retires it
+(denoise.cpp:252-280,326-331), and every state borrows the one static model (49-51,267).  A batched context advances B
+streams in lock-step; pn_ctx_reset_streams re-initialises chosen slots on the device while the others keep running, and
+the packed device weights are shared by every context of the same model content / device / network mode."""
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from percepnet_amd import api, build, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    m = api.Model(blob)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("mode", [api.NN_STRICT, api.NN_MFMA, api.NN_MFMA_X3, api.NN_MFMA_F16], ids=["strict", "mfma", "x3", "f16"])
+def test_slot_reset_at_frame_37_equals_a_fresh_stream_started_there(model, oracle, mode):
+    """300 streams; at frame 37 (history ring slot 1 of 12, look-ahead slot 1 of 6, conv slots 2 of 5 / 1 of 3, odd GRU
+    half) slots 5, 130 and 299 end their call and start a new one.  From there on those slots must produce exactly what a
+    FRESH context produces for the new streams from its frame 0 (bit for bit: same kernel family, and in STRICT mode also
+    the CPU oracle's bits), and every other slot must be bit-identical to a run in which nothing was reset."""
+    B, T, T0 = 300, 60, 37
+    ids = [5, 130, 299]
+    pcm = synth.synth_batch(B, T)
+    fresh = synth.synth_batch(len(ids), T - T0, first_stream=1000)          # the new calls
+    feed = pcm.copy()
+    for k, s in enumerate(ids):
+        feed[s, T0 * 480:] = fresh[k]
+    ref_ctx = api.Context(model, B, nn_mode=mode)
+    ref = [ref_ctx.process_i16(pcm[:, t * 480:(t + 1) * 480]) for t in range(T)]
+    ref_ctx.close()
+    small = api.Context(model, len(ids), nn_mode=mode)
+    exp = [small.process_i16(fresh[:, t * 480:(t + 1) * 480]) for t in range(T - T0)]
+    small.close()
+    ctx = api.Context(model, B, nn_mode=mode)
+    others = np.setdiff1d(np.arange(B), ids)
+    for t in range(T):
+        if t == T0:
+            ctx.reset_streams(ids)
+        out, gr = ctx.process_i16(feed[:, t * 480:(t + 1) * 480])
+        assert np.array_equal(out[others], ref[t][0][others]), t
+        assert np.array_equal(gr[others].view(np.uint32), ref[t][1][others].view(np.uint32)), t
+        if t >= T0:
+            assert np.array_equal(out[ids], exp[t - T0][0]), t
+            assert np.array_equal(gr[ids].view(np.uint32), exp[t - T0][1].view(np.uint32)), t
+    ctx.close()
+    if mode == api.NN_STRICT:
+        for k in range(len(ids)):
+            ro, rg = oracle.run_pcm(fresh[k])
+            got = np.concatenate([exp[t][0][k] for t in range(1, T - T0)])
+            assert np.array_equal(got, ro) and np.array_equal(np.stack([exp[t][1][k] for t in range(T - T0)]), rg)
+
+
+def test_reset_streams_argument_checks_and_pipelined_path(model):
+    """Out-of-range ids are refused; on the pipelined host path the reset lands between the frames submitted before and
+    after it (results equal the synchronous path)."""
+    import ctypes
+    B, T = 6, 9
+    pcm = synth.synth_batch(B, T)
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    with pytest.raises(api.PercepNetError):
+        ctx.reset_streams([0, B])
+    with pytest.raises(api.PercepNetError):
+        ctx.reset_streams([-1])
+    ctx.reset_streams([])
+    sync = []
+    for t in range(T):
+        if t == 4:
+            ctx.reset_streams([1, 1, 4])
+        sync.append(ctx.process_i16(pcm[:, t * 480:(t + 1) * 480])[0])
+    ctx.reset()
+    L = ctx.L
+    n = B * 480
+    bufs = [(L.pn_host_alloc(n * 2), L.pn_host_alloc(n * 2)) for _ in range(T)]
+    for t in range(T):
+        ctypes.memmove(bufs[t][0], np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480]).ctypes.data, n * 2)
+        if t == 4:
+            ctx.reset_streams([1, 4])
+        ctx.submit_host_i16(bufs[t][0], bufs[t][1])
+    ctx.host_wait()
+    for t in range(T):
+        got = np.ctypeslib.as_array(ctypes.cast(bufs[t][1], ctypes.POINTER(ctypes.c_int16)), shape=(B, 480))
+        assert np.array_equal(got, sync[t]), t
+    for a, b in bufs:
+        L.pn_host_free(a); L.pn_host_free(b)
+    ctx.close()
+
+
+def test_contexts_of_one_model_share_the_device_weights(blob):
+    """The reference binds every state to one static model (zero copies).  Here the first context of a (model content,
+    device, mode) uploads and re-packs the 32 MB once; every later one — also through a second pn_model handle holding
+    the same arrays — points at that copy: its footprint excludes the weights and it is created faster."""
+    m1, m2 = api.Model(blob), api.Model(blob)
+    t0 = time.perf_counter(); c1 = api.Context(m1, 64); t1 = time.perf_counter()
+    c2 = api.Context(m2, 64); t2 = time.perf_counter()
+    assert c1.describe()["weights"] == "own" and c2.describe()["weights"] == "shared"
+    assert c1.device_bytes() - c2.device_bytes() > 30 << 20            # 31.85 MB of weights + biases
+    print(f"\ncreate: first context {1e3 * (t1 - t0):.0f} ms (self-tests, re-pack, upload), second {1e3 * (t2 - t1):.0f} ms")
+    c3 = api.Context(m1, 64, nn_mode=api.NN_STRICT)                    # another mode: another layout, its own copy
+    assert c3.describe()["weights"] == "own"
+    pcm = synth.synth_batch(64, 3)
+    a = [c1.process_i16(pcm[:, t * 480:(t + 1) * 480])[0] for t in range(3)]
+    c1.close()                                                         # the copy outlives its creator while c2 uses it
+    c1b = api.Context(m1, 64)
+    assert c1b.describe()["weights"] == "shared"
+    for c in (c2, c1b):
+        for t in range(3):
+            assert np.array_equal(c.process_i16(pcm[:, t * 480:(t + 1) * 480])[0], a[t])
+    c2.close(); c1b.close(); c3.close()
+    c4 = api.Context(m2, 64)                                           # last user gone: the copy was freed, this one is new
+    assert c4.describe()["weights"] == "own"
+    c4.close(); m1.close(); m2.close()
+
+
+def test_cli_slot_queue_reuses_slots_of_finished_pairs(blob, oracle, tmp_path):
+    """percepnet_run --slots 2 with five recordings of different lengths (one shorter than a frame): two concurrent streams,
+    a finished pair's slot is re-initialised on the device and taken over by the next waiting pair.  Every output equals
+    the reference CLI's for that file alone (STRICT: bit for bit)."""
+    exe = build.RUN
+    (tmp_path / "m.pnw").write_bytes(blob)
+    lens = [9, 4, 17, 0, 6]
+    ins = [synth.synth_stream(40 + i, n) if n else np.zeros(100, np.int16) for i, n in enumerate(lens)]
+    args = []
+    for i, x in enumerate(ins):
+        (tmp_path / f"i{i}.pcm").write_bytes(x.tobytes()); args += [f"i{i}.pcm", f"o{i}.pcm"]
+    r = subprocess.run([exe, "--model", "m.pnw", "--strict", "--slots", "2"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, x in enumerate(ins):
+        got = np.fromfile(tmp_path / f"o{i}.pcm", np.int16)
+        if lens[i] == 0:
+            assert got.size == 0
+        else:
+            assert np.array_equal(got, oracle.run_pcm(x)[0]), i
