@@ -242,23 +242,81 @@ def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
     return r
 
 
-def dsp_roofline(kt, B):
-    """HBM roofline of the DSP kernels (front end = every kernel family whose name starts with "fe_" or "frontend",
-    back end): algorithmic bytes per stream-frame from DESIGN.md §4.1 / SURVEY §8(d)."""
-    fe_ms = sum(v[0] / max(v[1], 1) for k, v in kt.items() if k.startswith(("frontend", "fe_")))
-    be = kt.get("backend", (0.0, 0))
-    out = {}
-    if fe_ms > 0:
-        by = B * (27 * 1024 + 9 * 1024)           # ~27 KB read + 9 KB written per stream-frame
-        out["frontend"] = {"bound": "hbm", "ms": round(fe_ms, 4), "achieved": round(by / (fe_ms * 1e-3) / 1e9, 1),
-                           "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(by / (fe_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
-                           "algorithmic_bytes": by}
-    if be[1]:
-        ms = be[0] / be[1]
-        by = B * (3200 * 2 + 272 + 1920 * 2 + 960)  # X, P spectra; g|r; synthesis memory r/w; int16 PCM out
-        out["backend"] = {"bound": "hbm", "ms": round(ms, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
-                          "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
-                          "algorithmic_bytes": by}
+# Per-kernel algorithmic bytes of the DSP kernels per stream-frame (what each kernel must move given the phase split; the
+# history window is read by three kernels, so their sum exceeds SURVEY 8(d)'s whole-pipeline minimum of 32.9 KB):
+#   fe_spec_in   int16 PCM in 960 + previous frame of the history 1920 (the look-ahead window) | history slot 1920 +
+#                look-ahead spectrum 3200 + band energies 144 written
+#   fe_pitch     pitch_buf view of the history 1728 x 4 = 6912 | period, gain, two features 16
+#   fe_spec_out  comb-tap window of the history for the longest period 5568 x 4 = 22272 + X 3200 + 2 x 144 band energies |
+#                comb-filtered spectrum 3200 + feature row 512 + silence flag 4
+#   backend      X 3200 + P 3200 + g|r 272 + synthesis memory 1920 + silence 4 | synthesis memory 1920 + int16 PCM 960
+DSP_KERNELS = {
+    "fe_spec_in": ("pn_fe_spec_in_kernel", 960 + 1920 + 1920 + 3200 + 144),
+    "fe_pitch": ("pn_fe_pitch_kernel", 6912 + 16),
+    "fe_spec_out": ("pn_fe_spec_out_kernel", 22272 + 3200 + 288 + 3200 + 512 + 4),
+    "backend": ("pn_backend_kernel", 3200 + 3200 + 272 + 1920 + 4 + 1920 + 960),
+}
+
+
+def pmc_kernel_counters(kernel_prefix, tag=""):
+    """{counter: average per launch} of one kernel from the committed, snapshot-matched PMC summary (the largest grid of
+    that kernel name), or (None, why)."""
+    import csv, glob
+    snap = kernels_snapshot()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_per_launch{tag}.csv")))
+    fresh = [f for f in files if open(f).readline().strip() == f"# kernels_snapshot={snap}"]
+    if not fresh:
+        return None, f"no PMC profile of kernels snapshot {snap} under profiles/"
+    rows = [l for l in open(fresh[-1]) if not l.startswith("#")]
+    recs = [r for r in csv.DictReader(rows) if r["kernel"].startswith(kernel_prefix) and "grid=" in r["kernel"]]
+    if not recs:
+        return None, f"{os.path.basename(fresh[-1])} has no rows for {kernel_prefix}"
+    g = max(int(r["kernel"].rsplit("grid=", 1)[1]) for r in recs)
+    return {r["counter"]: float(r["avg"]) for r in recs if r["kernel"].endswith(f"grid={g}")}, os.path.basename(fresh[-1])
+
+
+def dsp_roofline(kt, B, tag=""):
+    """HBM roofline of the DSP kernels, ONE OBJECT PER KERNEL: `achieved` = algorithmic bytes of that kernel / its HIP-event
+    time; `traffic` = HBM-side bytes per launch from the rocprofv3 counters of the same kernels (FETCH_SIZE x 2 — the gfx950
+    counter tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 B, MI355X_MICROARCH.md; these kernels
+    read their history, spectra and PCM rows with dwordx4 / dwordx2 loads, for which the correction was calibrated; the scalar
+    4-byte loads of fe_pitch's window are the uncalibrated remainder — + WRITE_SIZE as is), `traffic_gbs` the same over the
+    event time, `traffic_over_algorithmic` what the phase split and re-reads cost.  `frontend` / `dsp_total` lump them."""
+    out, tot_ms, tot_alg, tot_tr = {}, 0.0, 0, 0
+    for fam, (kname, per_stream) in DSP_KERNELS.items():
+        ms, n = kt.get(fam, (0.0, 0))
+        if not n:
+            continue
+        ms /= n
+        alg = B * per_stream
+        o = {"kernel": kname, "bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": alg,
+             "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+             "frac": round(alg / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
+        ctr, src = pmc_kernel_counters(kname, tag)
+        if ctr and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            tr = ctr["FETCH_SIZE"] * 1024 * 2 + ctr["WRITE_SIZE"] * 1024
+            o.update({"traffic": tr, "traffic_gbs": round(tr / (ms * 1e-3) / 1e9, 1), "traffic_frac_of_peak": round(tr / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                      "traffic_over_algorithmic": round(tr / alg, 3), "traffic_source": src})
+            if "SQ_LDS_BANK_CONFLICT" in ctr and ctr.get("SQ_LDS_IDX_ACTIVE"):
+                o["lds_bank_conflict_share"] = round(ctr["SQ_LDS_BANK_CONFLICT"] / ctr["SQ_LDS_IDX_ACTIVE"], 4)
+            tot_tr += tr
+        else:
+            o.update({"traffic": None, "traffic_source": src})
+        out[fam] = o
+        tot_ms += ms; tot_alg += alg
+    if out:
+        out["dsp_total"] = {"ms": round(tot_ms, 4), "algorithmic_bytes": tot_alg, "achieved": round(tot_alg / (tot_ms * 1e-3) / 1e9, 1),
+                            "frac": round(tot_alg / (tot_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4), "unit": "GB/s",
+                            "traffic": tot_tr or None, "traffic_over_algorithmic": round(tot_tr / tot_alg, 3) if tot_tr else None,
+                            "whole_pipeline_minimum_bytes": B * (62608 - 29696),
+                            "note": "per-kernel algorithmic bytes count the history window once per kernel that needs it; "
+                                    "whole_pipeline_minimum_bytes is SURVEY 8(d)'s 62 608 - 29 696 B per stream-frame"}
+    # the single-launch front ends (PERCEPNET_FE=mono|g2) have no per-phase kernels
+    fe = kt.get("frontend", (0.0, 0))
+    if fe[1]:
+        ms = fe[0] / fe[1]; by = B * (27 * 1024 + 9 * 1024)
+        out["frontend"] = {"bound": "hbm", "ms": round(ms, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3,
+                           "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4), "algorithmic_bytes": by}
     return out
 
 
@@ -272,6 +330,95 @@ def gpu_clock_mhz():
         return int(m.group(1)) if m else None
     except Exception:                         # noqa: BLE001 — a missing tool must not cost the bench line
         return None
+
+
+class ClockSampler:
+    """Shader clock (rocm-smi) sampled from a side thread while a loop runs: min / max / samples."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.vals, self._stop = period, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = gpu_clock_mhz()
+            if v:
+                self.vals.append(v)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set(); self._th.join(timeout=30)
+
+    def summary(self):
+        return {"sclk_mhz_min": min(self.vals), "sclk_mhz_max": max(self.vals), "sclk_samples": len(self.vals)} if self.vals else {}
+
+
+def percentiles(ms):
+    import numpy as np
+    a = np.asarray(ms, dtype=np.float64)
+    return {"p50": round(float(np.percentile(a, 50)), 4), "p99": round(float(np.percentile(a, 99)), 4), "max": round(float(a.max()), 4),
+            "mean": round(float(a.mean()), 4), "frames": int(a.size)}
+
+
+def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0):
+    """The real-time contract itself (reference main.cpp:30-39: one 480-sample frame per stream every 10 ms), not an
+    extrapolation from a mean: a frame of B streams arrives on the HOST every 10.000 ms for `seconds` and goes through the
+    pipelined host entry points (pn_submit_host_i16: pinned buffers, copy-in / compute / copy-out on three streams, two
+    frames in flight).  Frame t is submitted at its arrival time a_t = t0 + 10 ms x t (or as soon as the previous call
+    returns, if that is later); the call returns when frame t - 2 has been delivered.  A frame MISSES its deadline when the
+    system has fallen behind its input: the submit call for frame t returns after frame t + 1 has already arrived."""
+    import ctypes
+    import numpy as np
+    ctx = api.Context(model, B, device=dev_index, nn_mode=nn_mode)
+    L = ctx.L
+    n = B * FRAME
+    try:
+        src = synth.synth_batch(min(B, 64), 3, base_seed=synth.BASE_SEED + 31337)
+        bufs = []
+        for k in range(3):
+            hin, hout = L.pn_host_alloc(n * 2), L.pn_host_alloc(n * 2)
+            if not hin or not hout:
+                raise RuntimeError("pinned allocation failed")
+            fr = np.ascontiguousarray(src[np.arange(B) % src.shape[0], k * FRAME:(k + 1) * FRAME])
+            ctypes.memmove(hin, fr.ctypes.data, n * 2)
+            bufs.append((hin, hout))
+        for k in range(6):                                   # warm the pipeline (streams, staging buffers, clocks)
+            ctx.submit_host_i16(*bufs[k % 3])
+        ctx.host_wait()
+        N = int(seconds * 100)
+        period = 0.010
+        arrive = np.empty(N); ret = np.empty(N); start = np.empty(N)
+        with ClockSampler() as clk:
+            t0 = time.perf_counter() + 0.002
+            for t in range(N):
+                a_t = t0 + period * t
+                while True:                                  # sleep most of the wait, spin the last 300 us
+                    now = time.perf_counter()
+                    if now >= a_t:
+                        break
+                    if a_t - now > 0.0005:
+                        time.sleep(a_t - now - 0.0003)
+                arrive[t] = a_t; start[t] = now
+                ctx.submit_host_i16(*bufs[t % 3])
+                ret[t] = time.perf_counter()
+            ctx.host_wait()
+            t_end = time.perf_counter()
+        late = ret[:-1] - arrive[1:]                          # > 0: the call for frame t came back after frame t + 1 had arrived
+        backlog = start - arrive                              # how far behind its arrival a frame was submitted
+        out = {"streams": B, "seconds": round(t_end - t0, 3), "frames": N, "period_ms": 10.0,
+               "deadline_misses": int((late > 0).sum()), "max_lateness_ms": round(float(max(late.max(), 0.0)) * 1e3, 4),
+               "submit_call_ms": percentiles((ret - start) * 1e3), "submit_backlog_ms_max": round(float(backlog.max()) * 1e3, 4),
+               "finished_behind_schedule_ms": round((t_end - (t0 + period * N)) * 1e3, 4),
+               "path": "pn_submit_host_i16 (pinned host buffers, PCIe both ways inside the loop)"}
+        out.update(clk.summary())
+        return out
+    finally:
+        ctx.close()
 
 
 def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, traffic_tag):
@@ -316,7 +463,10 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
             "dtype": DTYPE_OF_MODE[nn_mode],
             "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, traffic_tag=traffic_tag),
-            "dsp_roofline": dsp_roofline(kt, B)}
+            "dsp_roofline": dsp_roofline(kt, B, traffic_tag),
+            "whole_pipeline_hbm": {"algorithmic_gbs": round(B * K / dt * (62608 + 31850256 / B) / 1e9, 1),
+                                   "frac_of_peak": round(B * K / dt * (62608 + 31850256 / B) / 1e12 / PEAK_HBM_TBS, 4),
+                                   "note": "SURVEY 8(d): bytes(B) = 62 608 + 31 850 256 / B per stream-frame at the measured rate"}}
 
 
 DTYPE_OF_MODE = {0: "f32", 1: "f32 (reference order, separate mul/add)", 2: "f16 GEMM operands, f32 accumulate/state/DSP",
@@ -369,9 +519,11 @@ def main():
                     help="skip the short side measurements of configs[1] (1024 streams) and configs[4] (fp16) at N = 1")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained-rate loop after the timed region")
     ap.add_argument("--sustained-seconds", type=float, default=5.0)
+    ap.add_argument("--no-realtime", action="store_true", help="skip the paced 10 ms-clock runs through the pipelined host path")
+    ap.add_argument("--realtime-seconds", type=float, default=10.0)
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
     ap.add_argument("--fp16", action="store_true",
-                    help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: <=3 LSB)")
+                    help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: bound 6 LSB, 4 measured over 1024 x 1000)")
     ap.add_argument("--x3", action="store_true",
                     help="split-precision network mode (PN_NN_MFMA_X3): fp32 operands as fp16 hi+lo pairs, 3 fp16 MFMA products, "
                          "fp32 accumulate; same parity bounds as the fp32 MFMA mode (tests/test_gpu_x3.py)")
@@ -513,27 +665,55 @@ def main():
             rl = gru_roofline(kt, B, a.fp16, desc, n_gpus, fps, traffic_tag=tag)
             if rl:
                 res["roofline"] = rl
-            res["dsp_roofline"] = dsp_roofline(kt, B)
+            res["dsp_roofline"] = dsp_roofline(kt, B, tag)
         if cpu is not None:
             res["cpu_baseline"] = cpu
         # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
         # are 0.2 s, shorter than the time the chip needs to settle on its power-limited clock.
         if world == 1 and not a.no_sustained and not a.strict:
             n_sus, ds, per = 0, 0.0, max(dt / K, 1e-6)
+            ev = []                                              # one event per frame, read after the loop: per-frame completion times
             torch.cuda.synchronize()
-            while ds < a.sustained_seconds:                      # chunks sized from the rate seen so far; one sync per chunk
-                n = max(K, int((a.sustained_seconds - ds) / per * 1.05) + 1)
-                t0 = time.perf_counter()
-                for i in range(n):
-                    ctx.process_i16_dev(frames[(n_sus + i) % T].data_ptr(), out.data_ptr(), None)
-                torch.cuda.synchronize()
-                ds += time.perf_counter() - t0
-                n_sus += n
-                per = ds / n_sus
+            with ClockSampler() as clk:
+                while ds < a.sustained_seconds:                  # chunks sized from the rate seen so far; one sync per chunk
+                    n = max(K, int((a.sustained_seconds - ds) / per * 1.05) + 1)
+                    t0 = time.perf_counter()
+                    for i in range(n):
+                        ctx.process_i16_dev(frames[(n_sus + i) % T].data_ptr(), out.data_ptr(), None)
+                        e = torch.cuda.Event(enable_timing=True); e.record(stream); ev.append((len(ev) == 0 or i == 0, e))
+                    torch.cuda.synchronize()
+                    ds += time.perf_counter() - t0
+                    n_sus += n
+                    per = ds / n_sus
+            # interval between the completions of consecutive frames = the time the GPU took for that frame (the queue is
+            # never empty inside a chunk; the first frame of a chunk follows a host synchronise and is left out)
+            frame_ms = [ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev)) if not ev[i][0]]
+            pc = percentiles(frame_ms) if frame_ms else {}
             res["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 4),
                                 "value": round(B * n_sus / ds / 100.0, 1), "unit": "streams",
-                                "sclk_mhz_at_end": gpu_clock_mhz(),
-                                "note": "no per-kernel events in this loop; the K-step figure above is the contract's"}
+                                "frame_ms_p50": pc.get("p50"), "frame_ms_p99": pc.get("p99"), "frame_ms_max": pc.get("max"),
+                                "frames_timed": pc.get("frames"), "sclk_mhz_at_end": gpu_clock_mhz(),
+                                "note": "no per-kernel events in this loop (one completion event per frame); the K-step figure above is "
+                                        "the contract's; frame_ms_* = intervals between consecutive frame completions on the GPU"}
+            res["sustained"].update(clk.summary())
+        # The real-time claim, measured: frames arriving every 10.000 ms on the host for >= 10 s through the pipelined host path,
+        # at this batch size and — while a run still misses deadlines — at smaller ones.  `realtime_streams_p99` = the
+        # largest batch tried that met every deadline with a 99th-percentile frame time under 10 ms.
+        if world == 1 and B == 65536 and not (a.strict or a.fp16 or a.x3 or a.no_sustained or a.no_realtime):
+            runs, ok = [], None
+            for b2 in (65536, 61440, 57344, 53248, 49152):
+                try:
+                    r = paced_realtime(api, synth, model, local_rank, b2, api.NN_MFMA, a.realtime_seconds)
+                except Exception as e:          # noqa: BLE001 — reported, not fatal
+                    runs.append({"streams": b2, "error": f"{type(e).__name__}: {e}"}); break
+                runs.append(r)
+                if r["deadline_misses"] == 0 and r["submit_call_ms"]["p99"] < 10.0 and r["finished_behind_schedule_ms"] < 10.0:
+                    ok = b2; break
+            res["realtime"] = {"paced_runs": runs, "realtime_streams_p99": ok,
+                               "contract": "one 480-sample frame per stream every 10 ms (reference src/main.cpp:30-39), frames arriving on the "
+                                           "host on a 10.000 ms clock, pipelined host path, zero deadline misses over the run"}
+            if "sustained" in res and res["sustained"].get("frame_ms_p99") is not None:
+                res["realtime"]["device_resident_frame_ms_p99_at_65536"] = res["sustained"]["frame_ms_p99"]
         # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
         # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
         # Only with the default headline workload at N = 1; a failure here never costs the headline line.

@@ -58,7 +58,11 @@ struct pn_ctx {
   PnLayerHost geom[PN_NLAYERS];
   DevLayer L[PN_NLAYERS];           // = weights->L (pointers into the shared copy)
   SharedWeights *weights = NULL; WeightsKey weights_key; bool weights_were_cached = false;
-  int *d_ids = NULL; int ids_cap = 0;    // pn_ctx_reset_streams: stream ids on the device
+  // pn_ctx_reset_streams: stream ids on the device, and a ring of pinned host copies (the H2D copy runs when the stream gets
+  // to it — frames may be in flight — so its source must outlive the call; slot k is reused once its copy has executed)
+  int *d_ids = NULL; int ids_cap = 0;
+  struct IdSlot { int *h = NULL; hipEvent_t ev = nullptr; } id_slot[4];
+  unsigned id_calls = 0;
   PnTables *tables; float *tansig;
   float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
   // fp16-operand variant only: shadow copies (2 bytes per element, same indexing) of the buffers the GEMMs read
@@ -190,6 +194,7 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
   for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void *p : c->allocs) hipFree(p);
+  for (auto &sl : c->id_slot) { if (sl.h) hipHostFree(sl.h); if (sl.ev) hipEventDestroy(sl.ev); }
   if (c->weights) {
     std::lock_guard<std::mutex> lk(g_weights_mu);
     if (--c->weights->refs == 0) {
@@ -362,15 +367,27 @@ extern "C" int pn_ctx_reset_streams(pn_ctx *c, const int32_t *ids, int n) {
   for (int i = 0; i < n; i++) if (ids[i] < 0 || ids[i] >= c->B) { pn_set_error("stream id %d out of range [0, %d)", ids[i], c->B); return -1; }
   PN_ON_DEVICE(c);
   if (c->ids_cap < n) {
-    int cap = n < 1024 ? 1024 : n; if (cap > c->B) cap = c->B > n ? c->B : n;
+    // (the old, smaller buffers stay in allocs until destroy: kernels of an earlier call may still be reading them)
+    const int cap = n < 1024 ? 1024 : n;
     int *p = NULL;
-    PN_HIP_CHECK(hipMalloc((void **)&p, (size_t)cap * sizeof(int)));      // (the old, smaller buffer stays in allocs until destroy:
-    c->allocs.push_back(p); c->d_ids = p; c->ids_cap = cap;                // kernels of an earlier call may still be reading it)
+    PN_HIP_CHECK(hipMalloc((void **)&p, (size_t)cap * sizeof(int)));
+    c->allocs.push_back(p); c->d_ids = p;
+    for (auto &sl : c->id_slot) {
+      if (sl.ev) PN_HIP_CHECK(hipEventSynchronize(sl.ev));
+      if (sl.h) hipHostFree(sl.h);
+      sl.h = NULL;
+      PN_HIP_CHECK(hipHostMalloc((void **)&sl.h, (size_t)cap * sizeof(int), hipHostMallocDefault));
+      if (!sl.ev) PN_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    c->ids_cap = cap;
   }
-  // a pageable source is staged before hipMemcpyAsync returns: the caller's array is free again, and the copy is ordered
-  // on the context's stream behind the frames already submitted and the previous call's kernels
-  std::vector<int32_t> tmp(ids, ids + n);
-  PN_HIP_CHECK(hipMemcpyAsync(c->d_ids, tmp.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  {
+    pn_ctx::IdSlot &sl = c->id_slot[c->id_calls++ & 3];
+    PN_HIP_CHECK(hipEventSynchronize(sl.ev));             // the copy issued from this slot four calls ago has executed
+    memcpy(sl.h, ids, (size_t)n * sizeof(int));
+    PN_HIP_CHECK(hipMemcpyAsync(c->d_ids, sl.h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PN_HIP_CHECK(hipEventRecord(sl.ev, c->stream));
+  }
   hipStream_t st = c->stream; const int *d = c->d_ids;
   const long long B = c->B, Bp = (long long)c->Bp;
   pn_launch_zero_rows(st, c->hist, PN_HIST_STRIDE, PN_HIST_STRIDE, 1, 0, d, n);

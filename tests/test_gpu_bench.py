@@ -28,7 +28,11 @@ def test_single_rank_line_has_measured_parity_and_roofline():
     assert r["config"]["distributed"].startswith("none")
     assert r["sustained"]["steps"] >= 8 and r["sustained"]["seconds"] >= 0.3 and r["sustained"]["value"] > 0
     assert r["config"]["kernel_families"]["gru"] == "batch" and r["config"]["kernel_families"]["dense"] == "small"   # 2048 streams
-    assert r["dsp_roofline"]["frontend"]["bound"] == "hbm" and 0 < r["dsp_roofline"]["frontend"]["frac"] < 1
+    for k in ("fe_spec_in", "fe_pitch", "fe_spec_out", "backend"):       # one roofline object per DSP kernel
+        assert r["dsp_roofline"][k]["bound"] == "hbm" and 0 < r["dsp_roofline"][k]["frac"] < 1, k
+        assert "traffic" in r["dsp_roofline"][k] and r["dsp_roofline"][k]["kernel"].startswith("pn_")
+    assert 0 < r["dsp_roofline"]["dsp_total"]["frac"] < 1
+    assert r["sustained"]["frame_ms_p99"] >= r["sustained"]["frame_ms_p50"] > 0 and r["sustained"]["frames_timed"] >= 4
     assert isinstance(r["max_abs_delta_vs_cpu_ref_lsb"], int) and r["max_abs_delta_vs_cpu_ref_lsb"] <= 1
     assert r["max_abs_delta_gr"] <= 2e-5
     assert r["parity"]["replay_of_timed_run_bit_identical"] is True

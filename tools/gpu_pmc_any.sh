@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/s$i -o k -- python $R/tools/kernel_times.py 65536 3 > $OUT/s$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/s$i -o k -- python $R/tools/kernel_times.py 65536 3 > $OUT/s$i.log 2>&1
 done
 python - <<PY
 import csv, collections, glob

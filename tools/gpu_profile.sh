@@ -8,11 +8,11 @@ OUT=$R/gpurun_out/prof$SUF
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-parity --no-sustained --no-other-configs $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $B --steps 5 --warmup 2 > $OUT/stats_bench.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_sq.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_sq2.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $B --steps 5 --warmup 2 > $OUT/stats_bench.json 2> $OUT/stats.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_write.err
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_sq.err
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -o bench -- $B --steps 2 --warmup 1 --no-profile > /dev/null 2> $OUT/pmc_sq2.err
 python $R/tools/summarize_prof.py $TAG --suffix "$SUF" --src $OUT --out $R/gpurun_out/prof_summary
 # the raw kernel trace of a full run is large: keep only the summaries
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
