@@ -83,7 +83,8 @@ def test_reset_streams_argument_checks_and_pipelined_path(model):
     n = B * 480
     bufs = [(L.pn_host_alloc(n * 2), L.pn_host_alloc(n * 2)) for _ in range(T)]
     for t in range(T):
-        ctypes.memmove(bufs[t][0], np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480]).ctypes.data, n * 2)
+        fr = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])          # (kept alive across the memmove)
+        ctypes.memmove(bufs[t][0], fr.ctypes.data, n * 2)
         if t == 4:
             ctx.reset_streams([1, 4])
         ctx.submit_host_i16(bufs[t][0], bufs[t][1])

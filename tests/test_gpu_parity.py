@@ -696,10 +696,54 @@ def test_extreme_inputs_strict_bit_exact(model, oracle):
     assert np.array_equal(out, ro)
     assert np.array_equal(gr.view(np.uint32), rg.view(np.uint32))
     assert (rs == 0).any() and (rs == 1).any()
-    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
-    _, gm = ctx.run_pcm(x)
+    # MFMA and split-precision modes: g/r within the mode's bound, PCM within 1 LSB as a CIRCULAR distance — the reference's
+    # cast wraps (main.cpp:36), so a sample whose float value sits at the +-32768 boundary may land on either side
+    for mode in (api.NN_MFMA, api.NN_MFMA_X3):
+        ctx = api.Context(model, B, nn_mode=mode)
+        om, gm = ctx.run_pcm(x)
+        ctx.close()
+        assert np.abs(gm - rg).max() <= GR_TOL, mode
+        d = np.abs(om.astype(np.int32) - ro.astype(np.int32))
+        assert np.minimum(d, 65536 - d).max() <= PCM_TOL_LSB, (mode, int(np.minimum(d, 65536 - d).max()))
+
+
+def test_float_api_huge_and_non_finite_inputs(model, oracle):
+    """rnnoise_process_frame takes arbitrary floats (the CLI only ever feeds |x| <= 1).  The reference has a defined x86
+    behaviour for everything it is fed — samples at 1e4 stay finite all the way (output ~700), at 1e9 the band energies
+    overflow and the stream is NaN from its first frame, pre-activations past the tanh table hit cvttss2si's INT_MIN
+    (vec.h:61) and the clamp's index 0; a NaN or an infinity poisons that stream's history and spectra for good.  STRICT mode must
+    follow the CPU oracle bit for bit on the finite streams, value-or-NaN for the poisoned ones, and the clean streams
+    sharing the batch (the same GEMM tiles) must not notice."""
+    T = 14
+    base = (synth.synth_batch(6, T).astype(np.float32) / 32768.0)
+    x = base.copy()
+    x[1] *= 1e4                                                   # finite all the way through (|out| ~ 700): bit-exact
+    x = np.concatenate([x, (base[1] * 1e9)[None]])                # 1e9: the CPU path itself turns into NaN in the first frame
+    x[2, 3 * 480 + 17] = np.nan
+    x[3, 4 * 480 + 100] = np.inf
+    x[4] = -1e9                                                   # DC at -1e9
+    x[5, 5 * 480 + 3] = -np.inf; x[5, 5 * 480 + 4] = np.inf
+    ref = [oracle.run_float(x[s]) for s in range(7)]
+    ctx = api.Context(model, 7, nn_mode=api.NN_STRICT)
+    same = lambda a, b: bool((((a == b) | (np.isnan(a) & np.isnan(b)))).all())
+    for f in range(T):
+        o, g = ctx.process_f32(x[:, f * 480:(f + 1) * 480])
+        for s in range(7):
+            ro, rg = ref[s][0][f * 480:(f + 1) * 480], ref[s][1][f]
+            if s in (0, 1):                                         # finite streams: the bits
+                assert np.array_equal(o[s].view(np.uint32), ro.view(np.uint32)), (f, s)
+                assert np.array_equal(g[s].view(np.uint32), rg.view(np.uint32)), (f, s)
+            else:                                                   # poisoned streams: equal values, NaN where the CPU has NaN
+                assert same(o[s], ro) and same(g[s], rg), (f, s)
     ctx.close()
-    assert np.abs(gm - rg).max() <= GR_TOL
+    assert np.isfinite(ref[0][0]).all() and np.isfinite(ref[1][0]).all() and np.abs(ref[1][0]).max() > 100          # the scenario is
+    assert all(not np.isfinite(ref[s][0]).all() for s in (2, 3, 4, 5, 6))                                        # what it claims
+    # the fp32 MFMA mode on the same batch: the clean stream beside the poisoned ones stays within its bounds
+    ctx = api.Context(model, 7, nn_mode=api.NN_MFMA)
+    for f in range(T):
+        o, g = ctx.process_f32(x[:, f * 480:(f + 1) * 480])
+        assert np.abs(g[0] - ref[0][1][f]).max() <= GR_TOL and np.abs(o[0] - ref[0][0][f * 480:(f + 1) * 480]).max() <= 2.0 / 32768, f
+    ctx.close()
 
 
 def test_maximum_size_batch_300k_streams(model, oracle):
