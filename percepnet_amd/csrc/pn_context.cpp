@@ -70,6 +70,7 @@ struct pn_ctx {
   float2 *yring, *Ps;              // yring: [6][B][400] look-ahead spectra (X of frame t = slot (t+1)%6)
   float *eyring;                   // [6][B][36] look-ahead band energies
   bool postfilter = false;         // optional envelope post-filter in the back end (pn_ctx_set_postfilter)
+  bool x3_sat = false;             // PERCEPNET_X3_SATCOUNT=1 (shadow-operand modes): count operand values clamped to the fp16 range
   int dsp_grid_cap = 0;            // > 0 only in the DSP self-test's temporary context: its DSP launches use that many blocks
   int *last_period, *silence;
   std::vector<void *> allocs;
@@ -349,8 +350,13 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
     memcpy(c->L, c->weights->L, sizeof(c->L));
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
+  if (selftest && (nn_mode == PN_NN_MFMA_X3 || nn_mode == PN_NN_MFMA_F16)) {       // (not for the self-tests' temporary contexts)
+    const char *e = getenv("PERCEPNET_X3_SATCOUNT");
+    c->x3_sat = e && atoi(e);
+  }
   if (selftest && nn_mode != PN_NN_STRICT && nn_selftest(c)) goto fail;
   if (selftest && dsp_selftest(c)) goto fail;
+  if (c->x3_sat && pn_x3_sat_set(1)) { pn_set_error("cannot enable the operand-saturation counter"); goto fail; }   // after the self-tests: starts at zero
   return c;
 fail:
   pn_ctx_destroy(c);
@@ -433,7 +439,14 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
                          x3 ? xg : (fam && c->small_gru ? "small" : "batch"), x3 ? xg : (fam && c->small ? "small" : "batch"),
                          c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
                          c->weights_were_cached ? "shared" : "own");
-  return (w < 0 || (size_t)w >= n) ? -1 : w;
+  if (w < 0 || (size_t)w >= n) return -1;
+  if (c->x3_sat) {                                        // debug: operand values clamped to +-65504 so far (device-wide counter)
+    DeviceGuard _dg(c->device);
+    hipStreamSynchronize(c->stream);
+    const int w2 = snprintf(buf + w, n - w, " x3_saturated=%lld", pn_x3_sat_read());
+    return (w2 < 0 || (size_t)(w + w2) >= n) ? -1 : w + w2;
+  }
+  return w;
 }
 extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c); PN_HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
 

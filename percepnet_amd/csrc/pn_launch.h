@@ -59,6 +59,8 @@ void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
                       int n_rows, int rg, int np);
 int pn_x3_rg_for(int n_rows);
+int pn_x3_sat_set(int enable);          // debug counter of operand values clamped to +-65504 (current device): reset + switch
+long long pn_x3_sat_read();             // ... and its value, or -1
 void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np);
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);

@@ -48,9 +48,31 @@ template <int RG> struct X3A { fvec4 h[RG], l[RG]; };      // one k-step of A fr
 __device__ __forceinline__ half8 x3_h8(const fvec4 &v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ half8 x3_h8(const uint4 &v) { return __builtin_bit_cast(half8, v); }
 
+// Debug counter of operand saturation (PERCEPNET_X3_SATCOUNT=1 at context creation; per device, cumulative): activations
+// beyond the fp16 range are CLAMPED to +-65504 when they become GEMM operands of the fp16-operand / split-precision modes
+// (weights beyond it are refused at context creation).  conv1 is a ReLU and unbounded, so a model can get there; the
+// counter makes it visible (pn_ctx_describe: x3_saturated=<values clamped so far>) instead of silent.
+__device__ int pn_x3_sat_enable = 0;
+__device__ unsigned long long pn_x3_sat_count = 0;
+int pn_x3_sat_set(int enable) {
+  const unsigned long long zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(pn_x3_sat_count), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(pn_x3_sat_enable), &enable, sizeof(enable)) == hipSuccess ? 0 : -1;
+}
+long long pn_x3_sat_read() {
+  unsigned long long n = 0;
+  return hipMemcpyFromSymbol(&n, HIP_SYMBOL(pn_x3_sat_count), sizeof(n)) == hipSuccess ? (long long)n : -1;
+}
+
 // hi/lo planes of eight consecutive fp32 values (operands beyond the fp16 range saturate instead of turning into NaNs)
 __device__ __forceinline__ void x3_split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
   half8 h, l;
+  if (pn_x3_sat_enable) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) n += (v[j] > 65504.f || v[j] < -65504.f) ? 1 : 0;
+    if (n) atomicAdd(&pn_x3_sat_count, (unsigned long long)n);
+  }
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const float c = __builtin_fminf(__builtin_fmaxf(v[j], -65504.f), 65504.f);

@@ -343,3 +343,34 @@ def test_shadow_operand_kernels_never_read_past_their_buffers():
     m = re.search(r"x3 vs strict: max\|dPCM\| (\d+) LSB .* max\|dg,r\| ([0-9.e+-]+), .* finite (\w+)", r.stdout)
     assert m, r.stdout[-1000:]
     assert int(m.group(1)) <= PCM_TOL_LSB and float(m.group(2)) <= GR_TOL and m.group(3) == "True", m.group(0)
+
+
+@pytest.mark.parametrize("mode", [api.NN_MFMA_X3, api.NN_MFMA_F16], ids=["x3", "f16"])
+def test_operand_saturation_is_counted_not_silent(blob, mode, monkeypatch):
+    """The shadow-operand modes carry GEMM operands as fp16 (pairs): an activation beyond +-65504 is CLAMPED when it
+    becomes an operand (weights beyond it are refused at creation).  conv1 is a ReLU and unbounded (rnn_train.py:107), so
+    a model can drive it there: with PERCEPNET_X3_SATCOUNT=1 the library counts every clamped operand value and
+    pn_ctx_describe reports the total — zero for the default model, positive (with finite outputs, no NaN) for a model
+    whose conv1 bias is 1e5."""
+    monkeypatch.setenv("PERCEPNET_X3_SATCOUNT", "1")
+    pcm = synth.synth_batch(8, 4)
+    m0 = api.Model(blob)
+    c0 = api.Context(m0, 8, nn_mode=mode)
+    for t in range(4):
+        c0.process_i16(pcm[:, t * 480:(t + 1) * 480])
+    assert c0.describe()["x3_saturated"] == "0"
+    c0.close(); m0.close()
+    lay = weights.unpack_blob(blob)
+    lay["conv1"]["bias"] = np.full_like(lay["conv1"]["bias"], 1e5)          # ReLU(1e5 + ...) > 65504 in every conv1 output
+    m1 = api.Model(weights.pack_blob(lay))
+    c1 = api.Context(m1, 8, nn_mode=mode)
+    for t in range(4):
+        out, gr = c1.process_i16(pcm[:, t * 480:(t + 1) * 480])
+        assert np.isfinite(gr).all()
+    n = int(c1.describe()["x3_saturated"])
+    assert n >= 4 * 8 * 512, n                                              # conv1's 512 outputs of 8 streams, every frame
+    c1.close(); m1.close()
+    monkeypatch.delenv("PERCEPNET_X3_SATCOUNT")
+    c2 = api.Context(api.Model(blob), 8, nn_mode=mode)
+    assert "x3_saturated" not in c2.describe()                              # the counter is a debugging aid, off by default
+    c2.close()
