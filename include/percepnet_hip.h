@@ -49,9 +49,11 @@ enum {
                         order (nnet.cpp:59-72) with fused instead of separate rounding */
   PN_NN_STRICT = 1,  /* one lane per (stream, neuron), separate mul and add in the reference's
                         order: bit-identical to the CPU reference; slow, for parity tests */
-  PN_NN_MFMA_F16 = 2,/* BASELINE configs[4]: GEMM operands (weights and activations) rounded to fp16,
-                        fp32 accumulation (v_mfma_f32_32x32x16_f16); everything else fp32.
-                        Tolerance re-stated: see DESIGN.md */
+  PN_NN_MFMA_F16 = 2,/* BASELINE configs[4]: the GEMM operands (weights and activations) of conv1, conv2, the five
+                        GRUs and fc_gb rounded to fp16, fp32 accumulation (v_mfma_f32_32x32x16_f16); fc (70 inputs)
+                        and fc_rb (K = 128) run on the fp32 kernels; bias, activations, gating, state, DSP fp32.
+                        Operands beyond +-65504 saturate (PERCEPNET_X3_SATCOUNT=1 counts them).
+                        Tolerance re-stated: DESIGN.md 4.2b (6 LSB bound, 4 measured) */
   PN_NN_MFMA_X3 = 3  /* split precision: every fp32 GEMM operand is carried as an fp16 (hi, lo) pair and every
                         product formed as lo*hi + hi*lo + hi*hi by three v_mfma_f32_32x32x16_f16 into an fp32
                         accumulator (operand error ~2^-22, below the reference's own accumulation rounding);

@@ -5,7 +5,7 @@
  * Pinning: the reference's own tests pin only the three toy NN kernels
  * (tests/testnnet.cpp:19-66 + tests/nnet_data_test.h); everything else is pinned by executing
  * the compiled reference (oracle/_ref, built from the untouched sources by oracle/Makefile):
- * tests/test_oracle_vs_ref.py requires this file to be BIT-EXACT against it, per stage and
+ * tests/test_oracle.py requires this file to be BIT-EXACT against it, per stage and
  * end to end (PCM and g/r tap), and tests/golden/ holds vectors produced by that build.
  *
  * Arithmetic contract: every float operation below is a separately rounded IEEE binary32 op in

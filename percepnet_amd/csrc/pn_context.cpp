@@ -181,7 +181,7 @@ static bool n16_rows_ok(int n_streams) {
 static int nn_selftest(pn_ctx *c);
 static int dsp_selftest(pn_ctx *c);
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru, int force_x3_rg = 0);
+                          int force_small, int force_small_gru, int force_x3_rg = 0, int force_n16 = -1);
 
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
@@ -274,7 +274,7 @@ fail_w:
 // force_small / force_small_gru: -1 = choose the network kernel family from the batch size (the public behaviour);
 // 0 / 1 = the self-test's temporary contexts run the SAME family as the context under test whatever their own size.
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru, int force_x3_rg) {
+                          int force_small, int force_small_gru, int force_x3_rg, int force_n16) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
   if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16 && nn_mode != PN_NN_MFMA_X3) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
@@ -336,7 +336,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   if (zero_state(c)) goto fail;
   for (int li = 0; li < PN_NLAYERS; li++) { c->geom[li] = model->L[li]; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL; }
   {   // the device copy of the weights: shared with every other context of this model content on this device in this mode
-    const bool n16 = (nn_mode == PN_NN_MFMA) && n16_rows_ok(n_streams);
+    const bool n16 = (nn_mode == PN_NN_MFMA) && (force_n16 >= 0 ? force_n16 != 0 : n16_rows_ok(n_streams));
     c->weights_key = std::make_tuple(model->content_hash, device, nn_mode, n16 ? 1 : 0);
     std::lock_guard<std::mutex> lk(g_weights_mu);
     auto it = g_weights.find(c->weights_key);
@@ -437,7 +437,7 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   const char *xg = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 3 ? "x3_rows64_paired" : xk) : (c->x3_rg == 3 ? "f16_rows64_paired" : xk);
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s weights=%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
                          x3 ? xg : (fam && c->small_gru ? "small" : "batch"), x3 ? xg : (fam && c->small ? "small" : "batch"),
-                         c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
+                         x3 ? (c->L[PN_L_FC_RB].wq ? "fc_gb:x3+fc_rb:n16" : "fc_gb:x3+fc_rb:fp32") : (c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch")), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
                          c->weights_were_cached ? "shared" : "own");
   if (w < 0 || (size_t)w >= n) return -1;
   if (c->x3_sat) {                                        // debug: operand values clamped to +-65504 so far (device-wide counter)
@@ -591,7 +591,7 @@ static void launch_rnn(pn_ctx *c) {
 // differs by more than 2e-5 (fp32 operands) / 4e-3 (fp16 operands, whose rounding the x3 weights amplify).  The verdict is cached for
 // the process; a self-test that cannot allocate its ~70 MB of temporaries is reported as SKIPPED, not as a failure.
 static std::mutex g_selftest_mu;
-static std::map<std::tuple<int, int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
+static std::map<std::tuple<int, int, int, int, int, int>, int> g_selftest_done;     // key -> 0 passed, 1 skipped
 
 pn_model *pn_model_from_sources(const struct PnLayerSrc *src);
 static pn_model *selftest_model() {
@@ -623,7 +623,8 @@ static pn_model *selftest_model() {
 static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : 0);
+  const int n16 = c->L[PN_L_FC_GB].wq != NULL;           // narrow layers on the 16x16x4 kernel (small batches) or on the batch GEMM
+  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : 0, n16);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
   const int rows = 192;
@@ -635,7 +636,7 @@ static int nn_selftest(pn_ctx *c) {
   bool oom = false;
   for (int pass = 0; pass < 2 && !rc; pass++) {          // pass 0: the kernel family under test; pass 1: STRICT kernels
     g_last_alloc_oom = false;
-    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru, c->x3_rg);
+    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru, c->x3_rg, n16);
     if (!cx[pass]) { rc = -1; oom = g_last_alloc_oom; break; }
     unsigned x = 12345u;
     for (int step = 0; step < 2 && !rc; step++) {

@@ -5,10 +5,11 @@
 // the M axis, with bias preload and the table activation / GRU gating fused in the epilogue.
 // The summation order is the reference's (sgemv_accum, nnet.cpp:59-72 / vec.h:102-135): start
 // from the bias, add input contributions k = 0..K-1, then recurrent ones; the reset-after GRU
-// (compute_gru, nnet.cpp:120-180) is evaluated in the same three steps as the reference
-// (z,r and tmp = b_rh + U_h h  ->  h = b_h + tmp*r, then += W_h x  ->  blend), which needs a
-// second sweep over x but keeps the chain order.  Only difference from the CPU path: fused
-// instead of separate rounding of each multiply-add.
+// (compute_gru, nnet.cpp:120-180) keeps four accumulators per output: z and r (bias -> W x -> U h, the reference's
+// chains), tmp = b_rh + U_h h, and hx = W_h x summed as its OWN k-ascending chain from 0 in the same sweep over x;
+// the candidate is b_h + tmp * r + hx.  The reference adds the W_h x products onto (b_h + tmp * r) one by one
+// (nnet.cpp:166-167): same terms, one different association — the single documented deviation from the
+// reference's order.  Other than that: fused instead of separate rounding of each multiply-add.
 //
 // Tiling: 256-thread blocks (4 waves); a block owns 128 streams x (NT x 32) output columns,
 // wave w owns rows [32w, 32w+32).  Per K-tile of 32 the A tile (activations, row-major in HBM)
@@ -539,10 +540,6 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
   }
 }
 
-#ifdef PN_NN_EXPERIMENTS
-#include "experimental/pn_nn_variants.inc"   // first-generation K loop and the wave-specialised variants (not built by default)
-#endif
-
 // ---- launchers -----------------------------------------------------------------------------------
 // Batches of at most this many streams run the small-batch kernel family (pn_nn_small.hip: one 32x32 tile and one
 // accumulator chain per wave, 3-4x more blocks), larger ones the batch-GEMM kernels above.  Same numerics either way.
@@ -578,14 +575,6 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
-#if defined(PN_NN_EXPERIMENTS) && defined(PN_NN_OLD_PIPE)
-  if (NT == 4)
-    hipLaunchKernelGGL(pn_dense_mfma_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-  else
-    hipLaunchKernelGGL(pn_dense_mfma_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-#else
   // the half-tile pipeline consumes K-tiles in pairs: every layer of the PercepNet topology (the only geometry a
   // context accepts, pn_context.cpp:check_geometry) has an even number of them (4, 20, 48, 80, 4)
   if (KT < 2 || (KT & 1)) { pn_set_error("pn_launch_dense: %d K-tiles (must be even)", KT); return; }
@@ -595,7 +584,6 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
   else
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
-#endif
 }
 
 void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
@@ -613,23 +601,6 @@ void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_o
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-#if defined(PN_NN_EXPERIMENTS) && defined(PN_NN_OLD_PIPE)
-  hipLaunchKernelGGL(pn_gru_mfma_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
-                     tansig, h_new, n_rows, n_mtiles);
-#elif defined(PN_NN_EXPERIMENTS) && defined(PN_NN_WS)
-#if PN_NN_WS == 2
-  {
-    const int n_mt2 = (n_rows + 2 * BM - 1) / (2 * BM);
-    const int grid2 = 8 * ((n_mt2 + 7) / 8) * NTn;
-    hipLaunchKernelGGL(pn_gru_mfma_ws_kernel<2>, dim3(grid2), dim3(768), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
-                       tansig, h_new, n_rows, n_mt2);
-  }
-#else
-  hipLaunchKernelGGL(pn_gru_mfma_ws_kernel<1>, dim3(grid), dim3(512), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
-                     tansig, h_new, n_rows, n_mtiles);
-#endif
-#else
   hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
-#endif
 }

@@ -872,6 +872,10 @@ void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const f
                         const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg, int np) {
   if (rg == 3) rg = 2;                 // the paired-phase form exists for the GRUs only
   const int tps = A.width[0] / 32, KT = tps * A.n;
+  // the K loop consumes k-tiles in pairs and clamps its prefetch to the last tile: an odd count would accumulate that
+  // tile twice; panels must be whole 32-column tiles of equal width (every layer of the fixed topology is: 20 / 48 / 80)
+  for (int j = 0; j < A.n; j++) if (A.width[j] != A.width[0]) { pn_set_error("pn_launch_dense_x3: unequal panel widths"); return; }
+  if ((A.width[0] & 31) || KT < 2 || (KT & 1)) { pn_set_error("pn_launch_dense_x3: %d k-tiles of panel width %d (need whole tiles, an even count)", KT, A.width[0]); return; }
   const int NT = pn_dense_x3_nt(N);
   const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg);
   const int n_cblocks = x3_ct_padded(N, NT) / NT;
@@ -904,6 +908,9 @@ void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const
                       int n_rows, int rg, int np) {
   const int tps = X.width[0] / 32, KTx = tps * X.n;
   const int NTn = N / 32;
+  for (int j = 0; j < X.n; j++) if (X.width[j] != X.width[0]) { pn_set_error("pn_launch_gru_x3: unequal panel widths"); return; }
+  if ((X.width[0] & 31) || (N & 31) || (KTx & 1) || (NTn & 1)) {   // k-tiles are consumed in pairs (x: 16 / 32, h: 16 / 4)
+    pn_set_error("pn_launch_gru_x3: %d input and %d recurrent k-tiles (need whole tiles, even counts)", KTx, NTn); return; }
   // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it
   // is written for the tanh candidate and needs more K tiles than epilogue steps, otherwise the 64-rows-per-wave kernel
   // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it

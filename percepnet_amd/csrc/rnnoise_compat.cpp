@@ -6,8 +6,9 @@
 // PfPKfP8_IO_FILE, ...).  This file defines functions with exactly those prototypes in the global
 // C++ namespace — the compiler emits exactly those symbols — plus extern "C" `_c` spellings.
 //
-// One DenoiseState = a batch-of-one context.  That is correct but launch-bound (13 kernel
-// launches and two PCIe hops per 10 ms frame); throughput lives in the batched pn_* API.
+// One DenoiseState = a batch-of-one context.  That is correct but launch-bound (15 kernel
+// launches and two PCIe hops per 10 ms frame); throughput lives in the batched pn_* API.  N handles of one model share
+// one device copy of the weights (pn_context.cpp: SharedWeights) and, when they borrow the same RNNModel, one host copy.
 #include "pn_common.h"
 #include "../../include/percepnet_hip.h"
 // the reference's own (C++-mangled) entry points: exported like the C-ABI (the library is built with -fvisibility=hidden)
