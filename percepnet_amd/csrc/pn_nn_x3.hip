@@ -506,7 +506,7 @@ extern "C" PN_EXPORT int pn_x3p_hwid_read(unsigned *out) {
 #ifndef PN_XP_PRIO
 #define PN_XP_PRIO 2
 #endif
-#define XP_EPI_STEPS 30                // barriers the epilogue + prologue steps of a phase use; the K loop must have more
+#define XP_EPI_STEPS 32                // barriers the epilogue + prologue steps of a phase use; the K loop must have more
 
 // KTx = k-tiles of the input panels, NTn = N / 32 = k-tiles of the recurrent operand = column tiles: compile-time, so that
 // every step of a phase is a straight-line piece of code with its own constants (register sets, ring slots, tile numbers)
@@ -690,84 +690,85 @@ __global__ __launch_bounds__(512, 1) void pn_gru_x3p_kernel(
       // the previous state for the blend waits in the wave's LDS slice (XP_HOLOAD / XP_HOSTASH of the prologue), and the new
       // state overwrites the W_h x accumulator (acc[rg][2]) as it is formed: nothing extra is live beside the accumulators
       const float *Hl = S.H[wave] + (4 * (lane >> 5)) * 32 + (lane & 31);
-      // chunk c = (row group c >> 3, output pair c & 7): stage A = arguments of z and r + their table reads,
-      // B = z, r, candidate pre-activation, its argument + table read, C = candidate, blend.  Step s runs
-      // C(s-2), B(s-1), A(s): every table value is read one barrier interval before it is used.
+      // The gating of the tile's 32 outputs per lane (value v = 16 rg + i) in three stages — A: arguments of z and r + their
+      // table reads; B: z, r, candidate pre-activation, its argument + table read; C: candidate, blend — spread EVENLY over
+      // the steps: stage A of value v runs in step (3 v) >> 2, B one step later, C two steps later (every table value is read
+      // one barrier interval before it is used), i.e. four stage-tasks (~130 instructions) per step over steps 0..25.  The
+      // first version ran a whole pair per step in 18 steps: those steps took three K-loop intervals each while the K
+      // group idled at the barrier, and the 14 remaining steps ran at the K loop's pace with the epilogue wave idle — the
+      // two phases ADDED (35 k cycles) instead of overlapping.
       X3Ts za[32], ra[32], ha[32];
       float zy[32], ry[32], hy[32], zv[32];
       XP_PARTNER(it + grp);                                    // group 0's partner runs its tile `it`, group 1's already `it + 1`
       // step s of the phase = barrier interval s of the partner's K phase: its weight staging first, then this group's own
-      // piece of epilogue / prologue work:  0..17 gating arithmetic (stage A of chunk s, B of s - 1, C of s - 2) | 17 next
-      // tile's first operands | 18..21 the tile leaves through the LDS stage (18: next tile's previous state requested) |
-      // 21, 25, 29 own weight tiles 0, 1, 2 into the ring (each loaded four steps before) | 23 biases | 24 previous state
+      // work:  0..25 gating | 22 next tile's first operands | 25, 28, 31 own weight tiles 0, 1, 2 into the ring (each loaded
+      // three steps before) | 26..29 the tile leaves through the LDS stage (26: next tile's previous state requested) |
+      // 30 biases | 31 previous state into its LDS slice
 #pragma unroll
       for (int s = 0; s < TT; s++) {
         XP_STAGE(s);
+        int n_reads = 0;                                       // table reads issued in this step for the next one
 #if !(defined(PN_XP_ABL) && (PN_XP_ABL & 1))       // timing ablation (results wrong): no gating arithmetic
-        if (s >= 2 && s <= 17) {
-          const int c = s - 2, rg = c >> 3, i0 = 2 * (c & 7);
 #pragma unroll
-          for (int e = 0; e < 2; e++) {
-            const int k = 2 * c + e, i = i0 + e;
-            const float hc = x3_ts_fin(ha[k], hy[k]);
-            const float hov = Hl[(32 * rg + (i & 3) + 8 * (i >> 2)) * 32];
-            float o = zv[k] * hov + (1.f - zv[k]) * hc;
-            x3_pin(o);
-            acc[rg][2][i] = o;
-          }
+        for (int v = 0; v < 32; v++) {
+          if (((3 * v) >> 2) + 2 != s) continue;
+          const int rg = v >> 4, i = v & 15;
+          const float hc = x3_ts_fin(ha[v], hy[v]);
+          const float hov = Hl[(32 * rg + (i & 3) + 8 * (i >> 2)) * 32];
+          float o = zv[v] * hov + (1.f - zv[v]) * hc;
+          x3_pin(o);
+          acc[rg][2][i] = o;
         }
-        if (s >= 1 && s <= 16) {
-          const int c = s - 1, rg = c >> 3, i0 = 2 * (c & 7);
 #pragma unroll
-          for (int e = 0; e < 2; e++) {
-            const int k = 2 * c + e, i = i0 + e;
-            const float z = .5f + .5f * x3_ts_fin(za[k], zy[k]);
-            const float r = .5f + .5f * x3_ts_fin(ra[k], ry[k]);
-            float hp = bh_e + acc[rg][3][i] * r;
-            hp = hp + acc[rg][2][i];
-            ha[k] = x3_ts_arg(hp);
-            hy[k] = S.tansig[ha[k].i];
-            zv[k] = z;
-            x3_pin(ha[k].x); x3_pin(ha[k].sb); x3_pin(zv[k]);
-          }
+        for (int v = 0; v < 32; v++) {
+          if (((3 * v) >> 2) + 1 != s) continue;
+          const int rg = v >> 4, i = v & 15;
+          const float z = .5f + .5f * x3_ts_fin(za[v], zy[v]);
+          const float r = .5f + .5f * x3_ts_fin(ra[v], ry[v]);
+          float hp = bh_e + acc[rg][3][i] * r;
+          hp = hp + acc[rg][2][i];
+          ha[v] = x3_ts_arg(hp);
+          hy[v] = S.tansig[ha[v].i];
+          zv[v] = z;
+          x3_pin(ha[v].x); x3_pin(ha[v].sb); x3_pin(zv[v]);
+          n_reads += 1;
         }
-        if (s <= 15) {
-          const int c = s, rg = c >> 3, i0 = 2 * (c & 7);
 #pragma unroll
-          for (int e = 0; e < 2; e++) {
-            const int k = 2 * c + e, i = i0 + e;
-            za[k] = x3_ts_arg(.5f * acc[rg][0][i]);
-            ra[k] = x3_ts_arg(.5f * acc[rg][1][i]);
-            zy[k] = S.tansig[za[k].i];
-            ry[k] = S.tansig[ra[k].i];
-            x3_pin(za[k].x); x3_pin(za[k].sb); x3_pin(ra[k].x); x3_pin(ra[k].sb);
-          }
+        for (int v = 0; v < 32; v++) {
+          if (((3 * v) >> 2) != s) continue;
+          const int rg = v >> 4, i = v & 15;
+          za[v] = x3_ts_arg(.5f * acc[rg][0][i]);
+          ra[v] = x3_ts_arg(.5f * acc[rg][1][i]);
+          zy[v] = S.tansig[za[v].i];
+          ry[v] = S.tansig[ra[v].i];
+          x3_pin(za[v].x); x3_pin(za[v].sb); x3_pin(ra[v].x); x3_pin(ra[v].sb);
+          n_reads += 2;
         }
 #endif
-        if (s == 17) XP_PRO0(it + 1);
-        if (s == 18 || s == 20) {
-          const int rg = (s - 18) >> 1;
+        if (s == 22) XP_PRO0(it + 1);
+        if (s == 26 || s == 28) {
+          const int rg = (s - 26) >> 1;
           float vo[16];
 #pragma unroll
           for (int i = 0; i < 16; i++) vo[i] = acc[rg][2][i];
           x3_stage_write(T, vo, lane);
           x3_stage_store<NP>(T, 0, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
-          if (s == 18) XP_HOLOAD();                            // every blend has read the wave's slice
+          if (s == 26) XP_HOLOAD();                            // every blend has read the wave's slice
         }
-        if (s == 19 || s == 21) {
-          const int rg = (s - 19) >> 1;
+        if (s == 27 || s == 29) {
+          const int rg = (s - 27) >> 1;
           x3_stage_store<NP>(T, 1, h_new, N, nt_e * 32, N, row0 + 32 * rg, n_rows, Sx, srow + 32 * rg, lane);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
-        if (s == 21) XP_PRO1(0);
-        if (s == 23) XP_PRO2();
-        if (s == 24) XP_HOSTASH();
-        if (s == 25) XP_PRO1(1);
-        if (s == 29) XP_PRO1(2);
-        // the barrier: the table reads issued for the next step — 4 by stage A, 2 by stage B — stay in flight across it
+        if (s == 25) XP_PRO1(0);
+        if (s == 28) XP_PRO1(1);
+        if (s == 30) XP_PRO2();
+        if (s == 31) { XP_PRO1(2); XP_HOSTASH(); }
+        // the barrier: the table reads issued for the next step stay in flight across it
         if (s == TT - 1) __syncthreads();                      // the group's ring slots 0, 1, 2 are complete for its K phase
-        else if (s == 0) XP_BARN(4); else if (s <= 15) XP_BARN(6); else if (s == 16) XP_BARN(2); else XP_BAR();
+        else if (n_reads == 0) XP_BAR(); else if (n_reads == 1) XP_BARN(1); else if (n_reads == 2) XP_BARN(2);
+        else if (n_reads == 3) XP_BARN(3); else if (n_reads == 4) XP_BARN(4); else if (n_reads == 5) XP_BARN(5); else XP_BARN(6);
       }
     }
 #ifdef PN_X3_CLOCKS

@@ -77,6 +77,35 @@ __global__ __launch_bounds__(512) void probe(float *__restrict__ out, long long 
     float d[16];
     for (int c = 0; c < 16; c++) d[c] = lane * 0.01f + c;
     const long long t0 = __builtin_readcyclecounter();
+    if (comp_mode == 11 || comp_mode == 12) {
+      // tight loops (no mode dispatch inside): 480 instructions per 10 iterations' worth of the others, so that the loop
+      // overhead does not hide the issue rate.  11: 16 independent v_mul_f32 chains; 12: the epilogue's mix (and / mul / add /
+      // floor / cvt / med3 / lshl_add) on 16 independent chains
+      for (int it = 0; it < iters / 10; it++) {
+        if (comp_mode == 11) {
+#pragma unroll
+          for (int q = 0; q < 30; q++) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(d[c]) : "v"(k.x));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+              int t;
+              asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(d[c]));
+              asm volatile("v_mul_f32 %0, %0, %1" : "+v"(d[c]) : "v"(k.x));
+              asm volatile("v_add_f32 %0, %0, %1" : "+v"(d[c]) : "v"(k.y));
+              asm volatile("v_floor_f32 %0, %1" : "=v"(y0) : "v"(d[c]));
+              asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(t) : "v"(y0));
+              asm volatile("v_med3_i32 %0, %0, 0, %1" : "+v"(t) : "v"(200));
+              i0 += t;
+            }
+          }
+        }
+      }
+    } else
     // 48 instructions per iteration in every mode
     for (int it = 0; it < iters; it++) {
       if (comp_mode == 1) {               // packed f32: four independent chains
@@ -154,13 +183,14 @@ int main(int argc, char **argv) {
   hipMalloc(&out, (size_t)nblk * 512 * 4); hipMalloc(&cyc, nblk * 8 * 8);
   long long *h = (long long *)malloc(nblk * 8 * 8);
   const char *mn[6] = {"no MFMA", "MFMA acc in ArchVGPRs", "MFMA acc in AccVGPRs", "MFMA + ds_read_b128 / 6", "12 MFMA + s_barrier", "s_barrier only"};
-  const char *cn[11] = {"idle", "v_pk_mul/add_f32", "v_mul/add_f32", "and/med3/sub/lshl_add", "floor/cvt", "ds_read_b32 + 3 f32",
+  const char *cn[13] = {"idle", "v_pk_mul/add_f32", "v_mul/add_f32", "and/med3/sub/lshl_add", "floor/cvt", "ds_read_b32 + 3 f32",
                        "dense v_mul_f32 (16 chains)", "dense mul/add/and/floor",
-                       "64 v_mul + s_barrier", "s_barrier only", "32 v_mul + s_barrier"};
+                       "64 v_mul + s_barrier", "s_barrier only", "32 v_mul + s_barrier",
+                       "TIGHT dense v_mul_f32 (16 chains)", "TIGHT and/mul/add/floor/cvt/med3 (16 chains)"};
   for (int mm = 0; mm < 6; mm++)
-    for (int cm = 0; cm < 11; cm++) {
+    for (int cm = 0; cm < 13; cm++) {
       if (mm == 0 && cm == 0) continue;
-      if ((mm >= 4) != (cm >= 8)) continue;           // barrier-coupled modes only with each other
+      if ((mm >= 4) != (cm >= 8 && cm <= 10)) continue;           // barrier-coupled modes only with each other
       for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(probe, dim3(nblk), dim3(512), 0, 0, out, cyc, iters, mm, cm);
       hipDeviceSynchronize();
       hipMemcpy(h, cyc, nblk * 8 * 8, hipMemcpyDeviceToHost);
