@@ -309,6 +309,7 @@ def dsp_roofline(kt, B, tag=""):
                             "frac": round(tot_alg / (tot_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4), "unit": "GB/s",
                             "traffic": tot_tr or None, "traffic_over_algorithmic": round(tot_tr / tot_alg, 3) if tot_tr else None,
                             "whole_pipeline_minimum_bytes": B * (62608 - 29696),
+                            "traffic_over_whole_pipeline_minimum": round(tot_tr / (B * (62608 - 29696)), 3) if tot_tr else None,
                             "note": "per-kernel algorithmic bytes count the history window once per kernel that needs it; "
                                     "whole_pipeline_minimum_bytes is SURVEY 8(d)'s 62 608 - 29 696 B per stream-frame"}
     # the single-launch front ends (PERCEPNET_FE=mono|g2) have no per-phase kernels
