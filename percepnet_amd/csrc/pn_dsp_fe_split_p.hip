@@ -7,19 +7,24 @@
 //        on the spectral-in kernel of the same frame), last_period / last_gain of the previous frame
 //   out: last_period (the pitch index the spectral-out kernel filters at), last_gain, features 68 (period) and 69 (corr)
 //
-// What the measurements of round 3 say about this work (profiles/r03a_valu_issue_probe.log): a lone wave issues one
-// instruction per 4.5 cycles whatever its kind and a dependent add costs no more than an independent one — the serial
-// chains are ISSUE-bound, not latency-bound; two waves per SIMD double the rate; from there on the CU-wide LDS pipe is
-// the limiter (a ds_read_b32 costs two LDS cycles per wave-instruction, a bank conflict doubles it).  So this kernel is
-// built for (a) two waves per SIMD: 5056 bytes of LDS per stream (two 16-stream blocks per CU) and <= 256 registers
-// without spills, and (b) few LDS cycles: the 4x-decimated cross-correlation keeps a sliding window of its per-lane
-// operand in registers (each lane owns 11 CONSECUTIVE lags: one new value per step serves 11 multiply-adds), the
-// whitening FIR runs in place (descending, no second buffer), the sparse fine search never materialises its 294-entry
-// correlation array, and yy_lookup values are captured in flight instead of being stored.
+// What the measurements say about this work (profiles/r03a_valu_issue_probe.log, profiles/r04p_fe_pitch_variants.log): a
+// lone wave issues one instruction per 4.5 cycles whatever its kind and a dependent add costs no more than an independent
+// one — the serial chains are ISSUE-bound per wave, not latency-bound; two waves per SIMD double the rate; what is left is
+// shared between the CU-wide LDS pipe and every exposed LDS round trip (~150 cycles).  So this kernel is built for
+// (a) two waves per SIMD: 5056 bytes of LDS per stream (two 16-stream blocks per CU) and <= 256 registers;
+// (b) few instructions per chain step: the 4x-decimated cross-correlation keeps a sliding window of its per-lane operand
+//     in registers (each lane owns 11 CONSECUTIVE lags: one new value per step serves 11 multiply-adds), the whitening FIR
+//     runs in place, the sparse fine search never materialises its 294-entry correlation array;
+// (c) few LDS cycles and no LDS round trip inside a chain: an operand that is UNIFORM within a stream's 16 lanes is read
+//     once, lane-distributed (one conflict-free ds_read_b32 = 16 operands), and broadcast by the DPP modifier of the VALU
+//     instruction that consumes it (row_newbcast; row_shl for chains over consecutive lags).  Round 3 wrote such operands
+//     to a broadcast scratch and read them back four at a time on every lane, and the compiler sank those reads to just
+//     before their use: every fourth step of a recurrence waited for the LDS.
 //
 // Numerics contract: as pn_dsp_fe.hip — every arithmetic step is the reference's operation in the reference's order
 // with separate IEEE binary32 rounding (-ffp-contract=off; divide/sqrt correctly rounded; double islands in double);
-// every order-sensitive sum is the reference's sequential chain on one lane.  Bit-identical to the single-launch kernel.
+// every order-sensitive sum is the reference's sequential chain on one lane.  Bit-identical to the single-launch kernel
+// (an independent implementation of the same analysis: tests/test_gpu_parity.py compares the two).
 #define PN_FE_G 4
 #include "pn_dsp_fe_helpers.inc"
 #include <stdlib.h>
@@ -31,87 +36,102 @@
 
 // per-stream LDS slice, in floats
 #define FP_PBUF 0                       // [0,864)     decimated signal, whitened in place
-#define FP_SCR 864                      // [864,1264)  scratch:
-#define FP_XC (FP_SCR + 0)              //   [0,176)   coarse xcorr (lag 11 l + c), later p|q of yy_lookup (128)
-#define FP_D (FP_SCR + 176)             //   [176,324) d[] of the coarse best-pitch scan (148); later the 64-float d block of the fine scan
-#define FP_SQ (FP_SCR + 324)            //   [324,388) 64-float broadcast scratch
-#ifndef PN_FP_ROWS
-#define PN_FP_ROWS 0                    // 1: consecutive-lag chains (autocorrelation, final three) read one row per 12 steps and shift it with DPP
-                                        //    (fewer LDS cycles, one more VALU op per step: pays only while the LDS pipe is the limiter)
-#endif
-#ifndef PN_FP_PAIRS
-#define PN_FP_PAIRS 1                   // 1: remove_doubling's arbitrary-lag chains read aligned pairs (fp_chain2_pairs)
-#endif
+#define FP_SCR 864                      // [864,1264)  scratch: coarse xcorr (176, lag 11 l + c); the fine scan's 304 running energies;
+                                        //             yy_lookup's 384 running energies
 #define FP_SLICE 1264                   // 5056 bytes; 16 streams = 80 896 bytes per block, two blocks per CU
 
 
-// ---- serial chains with few LDS cycles --------------------------------------------------------------------------------
-// (profiles/r03c_fe_split_v1_pmc.txt: this kernel is bound by the CU's LDS pipe; 42 % of its LDS cycles were bank conflicts
-// of remove_doubling's per-lane arbitrary-lag reads, 9.5 conflict cycles per ds_read_b32.)
-
-// v[lane] -> v[lane + n] within the 16-lane row (n = 0..15; lanes whose source falls off the row keep garbage that
-// their caller never uses): v_mov_b32_dpp row_shl:n, which the compiler folds into the multiply that consumes it
+// ---- DPP operands ------------------------------------------------------------------------------------------------------
+// v[lane] -> v[lane + n] within the 16-lane row (lanes whose source falls off the row get 0, which their caller never
+// uses): v_mov_b32_dpp row_shl:n, folded by the compiler into the multiply that consumes it
 template <int n>
 __device__ __forceinline__ float fp_row_shl(float v) {
   if (n == 0) return v;
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + (n & 15), 0xf, 0xf, true));
 }
-// acc + sum_{j<N} a[j] * b[lane k: j + k], adds strictly in j order, for chains whose per-lane operands are CONSECUTIVE:
-// lane k of the group (k <= 15 - 11) correlates the group-uniform a[] against b[j + k].  One ds_read_b32 (the 16 lanes read
-// b[j0 .. j0+15]) then serves 12 steps through row shifts; a[] is read four steps per ds_read_b128 at a uniform address.
-// a + j0 must be 16-byte aligned for every block start j0 (multiples of 12: a itself 16-byte aligned).
+// the value held by lane n of this lane's 16-lane row (= of this stream's group): row_newbcast:n, folded into the add /
+// subtract / multiply that consumes it (v_add_f32_dpp ...)
+template <int n>
+__device__ __forceinline__ float fp_bc(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x150 + (n & 15), 0xf, 0xf, true));
+}
+// a product whose multiply carries a DPP operand, kept out of the SLP vectoriser's reach: paired into a v_pk_mul_f32 the
+// DPP operand would have to be materialised by a v_mov_b32_dpp first
+__device__ __forceinline__ float fp_mul_dpp(float dpp, float b) { float p = dpp * b; asm("" : "+v"(p)); return p; }
+#define FP_REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define FP_REP16(M) FP_REP12(M) M(12) M(13) M(14) M(15)
+
+// ---- inner-product chains (celt_inner_prod / xcorr_kernel, pitch.h:53-144): acc + sum_{j<N} a[j] * b[j], adds strictly
+// in j order, a[] uniform within the group, b[] per lane --------------------------------------------------------------------
+// All three forms run two register sets: the LDS reads of block k+1 are in flight while the serially dependent adds of
+// block k execute.  Two things keep it that way: the loops are branch-free (the last trip re-reads a block it does not
+// use — after a conditional load the wait at the join is for "everything", prefetch included), and a scheduling fence
+// follows every batch of loads (left alone the machine scheduler sinks a batch to just before its first use, merges it
+// with the next one and waits for both at once).
+#define FP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Per-lane operands at CONSECUTIVE lags: lane k of the group (k <= 15 - 11) correlates a[] against b[j + k].  One
+// ds_read_b32 (the 16 lanes read b[j0 .. j0+15]) serves 12 steps through row shifts inside the multiplies; a[] is read four
+// steps per ds_read_b128 at a uniform address (a + 12 blk 16-byte aligned for every blk: a itself 16-byte aligned).
+// Three register sets: the operands of a block are requested two blocks (24 steps) before their use.
+// (Measured alternatives, profiles/r04p_fe_pitch_variants.log: a[] through a row broadcast instead of the ds_read_b128 —
+// three instructions per step, no LDS traffic — is slower, this kernel is bound by instruction issue per wave.)
 template <int N>
 __device__ __forceinline__ float fp_chain_rows(const float *a, const float *b, int l, float acc) {
   static_assert(N % 4 == 0, "N");
-  constexpr int NB12 = N / 12, R = N % 12;
-  float4 a0[3], a1[3]; float v0, v1;
+  constexpr int NB = N / 12, R = N % 12, NT = NB / 3;
+  float4 a0[3], a1[3], a2[3]; float v0, v1, v2;
 #define FP_CR_LOAD(av, vv, blk) do {                                                            \
     _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (av)[q_] = *reinterpret_cast<const float4 *>(a + 12 * (blk) + 4 * q_); \
     (vv) = b[12 * (blk) + l];                                                                  \
   } while (0)
-#define FP_CR_MAC(av, vv) do {                                                                  \
-    acc = acc + (av)[0].x * fp_row_shl<0>(vv); acc = acc + (av)[0].y * fp_row_shl<1>(vv);       \
-    acc = acc + (av)[0].z * fp_row_shl<2>(vv); acc = acc + (av)[0].w * fp_row_shl<3>(vv);       \
-    acc = acc + (av)[1].x * fp_row_shl<4>(vv); acc = acc + (av)[1].y * fp_row_shl<5>(vv);       \
-    acc = acc + (av)[1].z * fp_row_shl<6>(vv); acc = acc + (av)[1].w * fp_row_shl<7>(vv);       \
-    acc = acc + (av)[2].x * fp_row_shl<8>(vv); acc = acc + (av)[2].y * fp_row_shl<9>(vv);       \
-    acc = acc + (av)[2].z * fp_row_shl<10>(vv); acc = acc + (av)[2].w * fp_row_shl<11>(vv);     \
-  } while (0)
+#define FP_CR_STEP(u) if ((u) < nst_) acc = acc + fp_mul_dpp(fp_row_shl<u>(vv_), ax_[u]);
+#define FP_CR_MAC(av, vv, nst) do {                                                             \
+    const float vv_ = (vv); constexpr int nst_ = (nst);                                         \
+    const float ax_[12] = {(av)[0].x, (av)[0].y, (av)[0].z, (av)[0].w, (av)[1].x, (av)[1].y, (av)[1].z, (av)[1].w,      \
+                           (av)[2].x, (av)[2].y, (av)[2].z, (av)[2].w};                         \
+    FP_REP12(FP_CR_STEP) } while (0)
   FP_CR_LOAD(a0, v0, 0);
+  FP_CR_LOAD(a1, v1, 1);
 #pragma unroll 1
-  for (int blk = 0; blk < NB12; blk += 2) {
-    if (blk + 1 < NB12) FP_CR_LOAD(a1, v1, blk + 1);
-    FP_CR_MAC(a0, v0);
-    if (blk + 2 < NB12) FP_CR_LOAD(a0, v0, blk + 2);
-    if (blk + 1 < NB12) FP_CR_MAC(a1, v1);
+  for (int t = 0; t < NT; t++) {
+    const int blk = 3 * t;
+    FP_CR_LOAD(a2, v2, blk + 2);
+    FP_FENCE();
+    FP_CR_MAC(a0, v0, 12);
+    FP_CR_LOAD(a0, v0, blk + 3 < NB ? blk + 3 : NB - 1);
+    FP_FENCE();
+    FP_CR_MAC(a1, v1, 12);
+    FP_CR_LOAD(a1, v1, blk + 4 < NB ? blk + 4 : NB - 1);
+    FP_FENCE();
+    FP_CR_MAC(a2, v2, 12);
   }
-  if (R) {                                          // R in {4, 8}
-    float4 ar[2]; float vr;
-#pragma unroll
-    for (int q = 0; q < R / 4; q++) ar[q] = *reinterpret_cast<const float4 *>(a + 12 * NB12 + 4 * q);
-    vr = b[12 * NB12 + l];
-    acc = acc + ar[0].x * fp_row_shl<0>(vr); acc = acc + ar[0].y * fp_row_shl<1>(vr);
-    acc = acc + ar[0].z * fp_row_shl<2>(vr); acc = acc + ar[0].w * fp_row_shl<3>(vr);
-    if (R > 4) {
-      acc = acc + ar[1].x * fp_row_shl<4>(vr); acc = acc + ar[1].y * fp_row_shl<5>(vr);
-      acc = acc + ar[1].z * fp_row_shl<6>(vr); acc = acc + ar[1].w * fp_row_shl<7>(vr);
-    }
+  if (NB % 3 >= 1) FP_CR_MAC(a0, v0, 12);            // blocks 3 NT, 3 NT + 1: requested by the last trip
+  if (NB % 3 == 2) FP_CR_MAC(a1, v1, 12);
+  if (R) {                                          // R in {4, 8}; reads up to a[N + 11 - R], b[N - R + 15]: inside the slice
+    FP_CR_LOAD(a2, v2, NB);
+    FP_CR_MAC(a2, v2, R);
   }
 #undef FP_CR_LOAD
+#undef FP_CR_STEP
 #undef FP_CR_MAC
   return acc;
 }
 
-// Two chains sharing the uniform operand, per-lane operands at ARBITRARY lags (remove_doubling's 28 + 2 inner products):
-// acc1 += a . b1, acc2 += a . b2, adds strictly in j order.  Every lane reads its operands as 8-byte ALIGNED pairs
-// (ds_read_b64: 64 banks, half the instructions) and picks the run that starts at its own parity (o1 / o2 = the parity of
-// the lane's first element: 1 = its run starts at the second float of the first pair): one v_cndmask per operand
-// instead of ~10 LDS bank-conflict cycles per scalar read.  b1 - o1, b2 - o2 must be 8-byte aligned.
+// Two chains sharing a[], per-lane operands at ARBITRARY lags (remove_doubling's 28 + 2 inner products): acc1 += a . b1,
+// acc2 += a . b2.  Every lane reads its operands as 8-byte ALIGNED pairs (ds_read_b64: 64 banks, half the instructions)
+// and picks the run that starts at its own parity (o1 / o2 = the parity of the lane's first element: 1 = its run starts at
+// the second float of the first pair): one v_cndmask per operand instead of ~10 LDS bank-conflict cycles per scalar read
+// (profiles/r03c_fe_split_v1_pmc.txt).  b1 - o1, b2 - o2 must be 8-byte aligned.  a[] is read
+// lane-distributed (one conflict-free ds_read_b32 per 16 steps) and broadcast inside the multiplies (v_mul_f32_dpp
+// row_newbcast).
+// (Measured alternative, profiles/r04p_fe_pitch_variants.log: the two chains as the halves of one v_pk_mul_f32 / v_pk_add_f32
+// per step with a[] from broadcast ds_read_b128 — fewer instructions in this phase, but the kernel as a whole 3 % slower.)
 template <int N>
-__device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1, bool o1, const float *b2, bool o2,
+__device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1, bool o1, const float *b2, bool o2, int l,
                                                 float &acc1, float &acc2) {
-  constexpr int U = 16, NF = N / U;
-  static_assert(N % U == 0 && NF % 2 == 0, "N");
+  constexpr int NF = N / 16, NP = NF / 2;
+  static_assert(N % 16 == 0 && NF % 2 == 0, "N");
   typedef float fp_f2 __attribute__((ext_vector_type(2)));
   // explicit LDS address space + volatile: each pair stays ONE ds_read_b64 (2 LDS cycles); as plain loads the compiler
   // either splits them (ds_read2_b32, alignment unproven) or merges two into ds_read2_b64 (8 cycles per two pairs)
@@ -119,91 +139,152 @@ __device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1,
   fp_lds_f2 *p1 = (fp_lds_f2 *)(b1 - (o1 ? 1 : 0)), *p2 = (fp_lds_f2 *)(b2 - (o2 ? 1 : 0));
   // the pairs are unpacked into scalars at once: element u of the lane's run is f[u] or f[u + 1] (ONE v_cndmask per
   // operand; left as vector lanes the compiler turns the choice into a dynamic vector index = a chain of 16 selects)
-  float4 a0[4], a1[4]; float r0[18], s0[18], r1[18], s1[18];
+  float a0, a1, r0[18], s0[18], r1[18], s1[18];
 #define FP_C2_LOAD(av, rv, sv, blk) do {                                                        \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) (av)[v_] = *reinterpret_cast<const float4 *>(a + 16 * (blk) + 4 * v_); \
+    (av) = a[16 * (blk) + l];                                                                   \
     _Pragma("unroll") for (int u_ = 0; u_ < 9; u_++) {                                          \
       const fp_f2 t1_ = p1[8 * (blk) + u_], t2_ = p2[8 * (blk) + u_];                           \
       (rv)[2 * u_] = t1_.x; (rv)[2 * u_ + 1] = t1_.y; (sv)[2 * u_] = t2_.x; (sv)[2 * u_ + 1] = t2_.y; } \
   } while (0)
-#define FP_C2_MAC(av, rv, sv) do {                                                              \
-    _Pragma("unroll") for (int v_ = 0; v_ < 4; v_++) {                                          \
-      const float ax_[4] = {(av)[v_].x, (av)[v_].y, (av)[v_].z, (av)[v_].w};                    \
-      _Pragma("unroll") for (int e_ = 0; e_ < 4; e_++) {                                        \
-        const float y1_ = o1 ? (rv)[4 * v_ + e_ + 1] : (rv)[4 * v_ + e_];                       \
-        const float y2_ = o2 ? (sv)[4 * v_ + e_ + 1] : (sv)[4 * v_ + e_];                       \
-        acc1 = acc1 + ax_[e_] * y1_;                                                            \
-        acc2 = acc2 + ax_[e_] * y2_;                                                            \
-      }                                                                                         \
-    }                                                                                           \
-  } while (0)
+#define FP_C2_STEP(u) {                                                                         \
+    const float y1_ = o1 ? rv_[(u) + 1] : rv_[u], y2_ = o2 ? sv_[(u) + 1] : sv_[u];              \
+    acc1 = acc1 + fp_mul_dpp(fp_bc<u>(av_), y1_); acc2 = acc2 + fp_mul_dpp(fp_bc<u>(av_), y2_); }
+#define FP_C2_MAC(av, rv, sv) do { const float av_ = (av); const float (&rv_)[18] = (rv); const float (&sv_)[18] = (sv); \
+    FP_REP16(FP_C2_STEP) } while (0)
   FP_C2_LOAD(a0, r0, s0, 0);
 #pragma unroll 1
-  for (int blk = 0; blk < NF; blk += 2) {
+  for (int p = 0; p < NP; p++) {
+    const int blk = 2 * p, nx = blk + 2 < NF ? blk + 2 : NF - 1;
     FP_C2_LOAD(a1, r1, s1, blk + 1);
+    FP_FENCE();
     FP_C2_MAC(a0, r0, s0);
-    if (blk + 2 < NF) FP_C2_LOAD(a0, r0, s0, blk + 2);
+    FP_C2_LOAD(a0, r0, s0, nx);
+    FP_FENCE();
     FP_C2_MAC(a1, r1, s1);
   }
 #undef FP_C2_LOAD
+#undef FP_C2_STEP
 #undef FP_C2_MAC
 }
 
-// find_best_pitch for the fine search (pitch.cpp:46-104 on the sparse xcorr of pitch.cpp:344-361): only the <= 10 lags
-// within +-2 of twice the two coarse candidates carry a correlation, every other entry is 0 and skipped by the
-// reference's `if (xcorr[i] > 0)`.  The running energy still visits all 294 candidates; each lane captures it at its own
-// candidate, then the candidates are replayed in ascending lag order through the reference's (best, second best) update.
-// cidx/cval/cact: this lane's candidate lag, max(-1, sum) and "inside [0,294)"; lanes >= 10 are inactive.
-__device__ __forceinline__ void fp_fine_best_pitch(const float *y, float *sq, float *dblk, int l, int gb, int cidx, float cval,
+// ---- find_best_pitch (pitch.cpp:46-104, float instantiation) ---------------------------------------------------------------
+// Group-uniform recurrence.  Everything that is not order-dependent is formed lane-parallel first with the reference's
+// roundings and stays lane-distributed in registers (element 16 w + u = lane u of register w): the squares y[j]^2 of the
+// initial energy, the window updates d[i] = y[i+LEN]^2 - y[i]^2 and the numerators num[i] = (xcorr[i]*1e-12)^2, with NaN
+// standing for "xcorr[i] <= 0: candidate skipped" (every comparison against NaN is false).  The serial part is the
+// running-energy add + clamp per candidate and, only when some candidate of a group of four beats the current second
+// best (in any of the wave's streams), the cross-multiplied comparisons and selects on the (best, second best) state.
+__device__ __forceinline__ float fp_syy_next(float sy, float dd) { const float t = sy + dd; return (1 > t) ? 1 : t; }
+#define FP_FBP_STEP(nm_, sy_, idx_) do {                                                            \
+    const float num = (nm_);                                                                        \
+    const bool c1 = num * bd1 > bn1 * (sy_);                                                        \
+    const bool c0 = c1 && (num * bd0 > bn0 * (sy_));                                                \
+    bn1 = c0 ? bn0 : (c1 ? num : bn1); bd1 = c0 ? bd0 : (c1 ? (sy_) : bd1); bp1 = c0 ? bp0 : (c1 ? (idx_) : bp1); \
+    bn0 = c0 ? num : bn0; bd0 = c0 ? (sy_) : bd0; bp0 = c0 ? (idx_) : bp0;                          \
+  } while (0)
+// four candidates i0_ + 4 g .. + 3 (operands: lanes 4 g .. 4 g + 3 of dw_ / nw_).  The state update re-broadcasts its
+// numerators from an opaque copy of nw_: were they the values of the test above, those would have to be materialised by
+// four v_mov_dpp on the hot path instead of riding inside the four multiplies.
+#define FP_SCAN_GROUP(g) do {                                                                       \
+    const float s0_ = Syy, s1_ = fp_syy_next(s0_, fp_bc<4 * (g)>(dw_)), s2_ = fp_syy_next(s1_, fp_bc<4 * (g) + 1>(dw_)), \
+                s3_ = fp_syy_next(s2_, fp_bc<4 * (g) + 2>(dw_));                                    \
+    Syy = fp_syy_next(s3_, fp_bc<4 * (g) + 3>(dw_));                                                \
+    const bool any_ = (fp_mul_dpp(fp_bc<4 * (g)>(nw_), bd1) > bn1 * s0_) | (fp_mul_dpp(fp_bc<4 * (g) + 1>(nw_), bd1) > bn1 * s1_) |   \
+                      (fp_mul_dpp(fp_bc<4 * (g) + 2>(nw_), bd1) > bn1 * s2_) | (fp_mul_dpp(fp_bc<4 * (g) + 3>(nw_), bd1) > bn1 * s3_); \
+    if (__ballot(any_)) {                                                                           \
+      float nx_ = nw_;                                                                              \
+      asm volatile("" : "+v"(nx_));                                                                 \
+      FP_FBP_STEP(fp_bc<4 * (g)>(nx_), s0_, i0_ + 4 * (g)); FP_FBP_STEP(fp_bc<4 * (g) + 1>(nx_), s1_, i0_ + 4 * (g) + 1); \
+      FP_FBP_STEP(fp_bc<4 * (g) + 2>(nx_), s2_, i0_ + 4 * (g) + 2); FP_FBP_STEP(fp_bc<4 * (g) + 3>(nx_), s3_, i0_ + 4 * (g) + 3); \
+    }                                                                                               \
+  } while (0);
+
+// coarse search (pitch.cpp:315-342): 147 candidates, len 240, on the 4x-decimated signal y_lp4[j] = y[2 j] read in place
+// Syy: the initial energy 1 + sum_{j<240} y_lp4[j]^2 (accumulated beside the cross-correlation that produced xcorr)
+__device__ __forceinline__ void fp_coarse_best_pitch(const float *xcorr, const float *y, int l, float Syy, int &bp0_out, int &bp1_out) {
+  constexpr int LEN = 240, MAXP = 147, NW = (MAXP + 15) / 16;
+  float dreg[NW], nreg[NW];
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const int i = l + 16 * w, ic = i < MAXP ? i : MAXP - 1;
+    const float a = y[2 * (ic + LEN)], c = y[2 * ic], xc = xcorr[ic];
+    dreg[w] = a * a - c * c;
+    float x16 = xc;
+    x16 *= 1e-12f;
+    nreg[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");
+  }
+  FP_FENCE();                                            // every operand read and formed before the serial part starts
+  float bn0 = -1.f, bn1 = -1.f, bd0 = 0.f, bd1 = 0.f; int bp0 = 0, bp1 = 1;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const float dw_ = dreg[w], nw_ = nreg[w];
+    const int i0_ = 16 * w;
+    FP_SCAN_GROUP(0)
+    if (16 * w + 4 < MAXP) { FP_SCAN_GROUP(1) }
+    if (16 * w + 8 < MAXP) { FP_SCAN_GROUP(2) }
+    if (16 * w + 12 < MAXP) { FP_SCAN_GROUP(3) }
+  }
+  bp0_out = bp0; bp1_out = bp1;
+}
+
+// fine search (pitch.cpp:344-372): only the <= 10 lags within +-2 of twice the two coarse candidates carry a correlation,
+// every other entry of the reference's xcorr[] is 0 and skipped by its `if (xcorr[i] > 0)`.  The running energy of
+// find_best_pitch still visits all 294 candidates, but it depends on the signal only — so it rides inside the chain that
+// computes the fine correlations (fp_fine_chain_scan: its add / compare / select fill issue slots beside that chain's
+// multiply-adds instead of waiting on each other in a loop of their own), lane u keeping the energy seen by candidates
+// == u (mod 16) (one select per step under a loop-invariant lane mask); the 320 values go to capbuf.
+//
+// acc + sum_{j<480} a[j] * b[j] (b[] per lane, sixteen scalars per block; a[] lane-distributed and broadcast inside the
+// multiplies, as in fp_chain2_pairs) and, beside it, Syy_{i+1} = MAX32(1, Syy_i + y[i+480]^2 - y[i]^2) for
+// i < 320 (candidates >= 294 repeat the last one; their values are never read), capbuf[i] = Syy_i
+__device__ __forceinline__ float fp_fine_chain_scan(const float *a, const float *b, const float *y, float *capbuf, int l, float Syy) {
+  constexpr int LEN = 480, MAXP = 294, NF = LEN / 16, NS = 20;        // NS: blocks that carry scan steps (even, >= 294 / 16)
+  float acc = 0.f;
+  float a0, a1, b0[16], b1[16], ya0, yc0, ya1, yc1;
+#define FP_FS_LOAD(av, bv, yav, ycv, blk, scan) do { (av) = a[16 * (blk) + l];                     \
+    _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) (bv)[u_] = b[16 * (blk) + u_];              \
+    if (scan) { const int i_ = 16 * (blk) + l, ic_ = i_ < MAXP ? i_ : MAXP - 1; (yav) = y[ic_ + LEN]; (ycv) = y[ic_]; } } while (0)
+#define FP_FS_STEP(u) acc = acc + fp_mul_dpp(fp_bc<u>(av_), bv_[u]);                               \
+    if (scan_) { capw_ = (l == (u)) ? Syy : capw_; Syy = fp_syy_next(Syy, fp_bc<u>(dw_)); }
+#define FP_FS_MAC(av, bv, yav, ycv, blk, scan) do {                                               \
+    const float av_ = (av); const float (&bv_)[16] = (bv); constexpr bool scan_ = (scan);         \
+    const float dw_ = scan_ ? (yav) * (yav) - (ycv) * (ycv) : 0.f; float capw_ = 0.f;             \
+    FP_REP16(FP_FS_STEP)                                                                          \
+    if (scan_) capbuf[16 * (blk) + l] = capw_; } while (0)
+  FP_FS_LOAD(a0, b0, ya0, yc0, 0, true);
+#pragma unroll 1
+  for (int p = 0; p < NS / 2; p++) {
+    const int blk = 2 * p;
+    FP_FS_LOAD(a1, b1, ya1, yc1, blk + 1, true);
+    FP_FENCE();
+    FP_FS_MAC(a0, b0, ya0, yc0, blk, true);
+    FP_FS_LOAD(a0, b0, ya0, yc0, blk + 2, true);            // block NS's scan operands are read and not used
+    FP_FENCE();
+    FP_FS_MAC(a1, b1, ya1, yc1, blk + 1, true);
+  }
+#pragma unroll 1
+  for (int p = NS / 2; p < NF / 2; p++) {
+    const int blk = 2 * p, nx = blk + 2 < NF ? blk + 2 : NF - 1;
+    FP_FS_LOAD(a1, b1, ya1, yc1, blk + 1, false);
+    FP_FENCE();
+    FP_FS_MAC(a0, b0, ya0, yc0, blk, false);
+    FP_FS_LOAD(a0, b0, ya0, yc0, nx, false);
+    FP_FENCE();
+    FP_FS_MAC(a1, b1, ya1, yc1, blk + 1, false);
+  }
+#undef FP_FS_LOAD
+#undef FP_FS_STEP
+#undef FP_FS_MAC
+  return acc;
+}
+
+// find_best_pitch of the fine search: the candidates are replayed in ascending lag order through the reference's (best,
+// second best) update.  cidx/cval/cact: this lane's candidate lag, max(-1, sum) and "inside [0,294)"; lanes >= 10 are
+// inactive; capbuf: the running energies left by fp_fine_chain_scan.
+__device__ __forceinline__ void fp_fine_best_pitch(const float *capbuf, int l, int gb, int cidx, float cval,
                                                    bool cact, int dup_lo, int &bp0_out, int &bp1_out) {
-  constexpr int LEN = 480, MAXP = 294, MP4 = 296;
-  // initial energy Syy = 1 + sum_{j<LEN} y[j]^2, j ascending (pitch.cpp:62-63); squares lane-parallel 64 at a time
-  float Syy = 1.0f;
-#pragma unroll 1
-  for (int blk = 0; blk < LEN / 64 + 1; blk++) {
-    float yv[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const int j = 64 * blk + l + L * w; yv[w] = y[j < LEN ? j : 0]; }
-    PN_WAVE_SYNC();
-#pragma unroll
-    for (int w = 0; w < 4; w++) sq[l + L * w] = yv[w] * yv[w];
-    PN_WAVE_SYNC();
-    if (blk < LEN / 64) Syy = fe_sum_sq<16>(sq, Syy);
-    else Syy = fe_sum_sq<(LEN % 64) / 4>(sq, Syy);
-  }
-  // running energy over the candidates, captured where this lane's candidate sits (before that candidate's update)
-  float cap = 0.f;
-#pragma unroll 1
-  for (int blk = 0; blk < (MP4 + 63) / 64; blk++) {
-    float dv[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const int i = 64 * blk + l + L * w, ic = i < MAXP ? i : MAXP - 1;
-      const float a = y[ic + LEN], c = y[ic];
-      dv[w] = a * a - c * c;
-    }
-    PN_WAVE_SYNC();
-#pragma unroll
-    for (int w = 0; w < 4; w++) dblk[l + L * w] = dv[w];
-    PN_WAVE_SYNC();
-    const int rel = cidx - 64 * blk;
-#pragma unroll
-    for (int h0 = 0; h0 < 16; h0 += 8) {
-      float4 d4[8];
-#pragma unroll
-      for (int v = 0; v < 8; v++) d4[v] = *reinterpret_cast<const float4 *>(dblk + 4 * (h0 + v));
-#pragma unroll
-      for (int v = 0; v < 8; v++) {
-        const float dd[4] = {d4[v].x, d4[v].y, d4[v].z, d4[v].w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          cap = (rel == 4 * (h0 + v) + e) ? Syy : cap;
-          const float t = Syy + dd[e];
-          Syy = (1 > t) ? 1 : t;
-        }
-      }
-    }
-  }
+  const float cap = capbuf[cact ? cidx : 0];            // running energy before this lane's candidate
+  PN_WAVE_SYNC();
   // candidates: positive correlation, not a repeat of a lane of the first window
   const bool cand = cact && cval > 0 && !(l >= 5 && cidx >= dup_lo && cidx <= dup_lo + 4);
   float x16 = cval;
@@ -224,13 +305,12 @@ __device__ __forceinline__ void fp_fine_best_pitch(const float *y, float *sq, fl
     const float n_r = __shfl(num, src), s_r = __shfl(cap, src);
     const int i_r = __shfl(cidx, src);
     const float nm = field ? n_r : __builtin_nanf("");      // NaN: no r-th candidate in this stream (every comparison false)
-    const bool c1 = nm * bd1 > bn1 * s_r;
-    const bool c0 = c1 && (nm * bd0 > bn0 * s_r);
-    bn1 = c0 ? bn0 : (c1 ? nm : bn1); bd1 = c0 ? bd0 : (c1 ? s_r : bd1); bp1 = c0 ? bp0 : (c1 ? i_r : bp1);
-    bn0 = c0 ? nm : bn0; bd0 = c0 ? s_r : bd0; bp0 = c0 ? i_r : bp0;
+    FP_FBP_STEP(nm, s_r, i_r);
   }
   bp0_out = bp0; bp1_out = bp1;
 }
+#undef FP_SCAN_GROUP
+#undef FP_FBP_STEP
 
 // xcorr[t] of the sparse fine correlation: the value of an active lane whose lag is t, else 0
 __device__ __forceinline__ float fp_sparse_at(int t, int gb, int cidx, float cval, bool cact) {
@@ -264,7 +344,10 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
       int base_slot = base_slot0, slice = slice0;
       asm volatile("" : "+v"(base_slot), "+v"(slice));     // (same for the LDS addresses: one base register + immediates)
       float *buf = SH + slice;
-      float *pbuf = buf + FP_PBUF, *raw = buf + FP_PBUF, *xcs = buf + FP_XC, *d1 = buf + FP_D, *sq64 = buf + FP_SQ;
+#ifdef PN_FE_CLOCKS
+      long long tmark_ = __builtin_readcyclecounter();
+#endif
+      float *pbuf = buf + FP_PBUF, *raw = buf + FP_PBUF, *scr = buf + FP_SCR, *xcs = buf + FP_SCR;
       // -- pitch_downsample (pitch.cpp:148-216) of pitch_buf == comb_buf[1632,3360): outputs 2m, 2m+1 need x[4m-1 .. 4m+3]
 #pragma unroll 1
       for (int half = 0; half < 2; half++) {
@@ -287,21 +370,20 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         }
       }
       PN_WAVE_SYNC();
+      FE_MARK(0);   // downsample
       // _celt_autocorr (celt_lpc.cpp:198-279): lane k holds lag k (lanes > 4 shadow lag 4)
       float ac[5];
       {
         const int lag = l < 4 ? l : 4;
-#if PN_FP_ROWS
         float ack = fp_chain_rows<860>(raw, raw, l, 0.f);     // lane k <= 4: sum_i raw[i] * raw[i + k]; lanes > 4 are never read
-#else
-        float ack = fe_chain<860>(raw, raw + lag, 0.f);
-#endif
+        FE_MARK(10);  // autocorrelation chain
         float d = 0;
         for (int i = lag + 860; i < 864; i++) d = d + raw[i] * raw[i - lag];
         ack += d;
 #pragma unroll
         for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, gb + k);
       }
+      FE_MARK(11);  // autocorrelation tail + gather
       ac[0] *= 1.0001f;
 #pragma unroll
       for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
@@ -343,6 +425,7 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         lpc2[3] = lpc[3] + .8f * lpc[2];
         lpc2[4] = .8f * lpc[3];
       }
+      FE_MARK(1);   // LPC
       // celt_fir5 (pitch.cpp:106-145) with zero memory == a pure 5-tap FIR: IN PLACE, highest index first — an output
       // only reads inputs at its own index and below, so descending blocks never read a value already overwritten;
       // inside a block all reads are issued before the first write
@@ -371,10 +454,12 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         PN_WAVE_SYNC();
       }
 
+      FE_MARK(2);   // whitening FIR
       // -- pitch_search (pitch.cpp:283-386): x_lp = pbuf+384, y = pbuf, len 960, max_pitch 588 ------------------------------
       // coarse (4x decimation, 147 lags x 240 steps): x_lp4[j] = pbuf[384+2j] (group-uniform), y_lp4[j] = pbuf[2j].
       // Lane l owns the 11 consecutive lags 11 l + c.  Twelve registers hold y_lp4[11 l + e] for e = j .. j+11 (register
       // e mod 12): step j uses e = j .. j+10 and then refills the register of e = j with e = j + 12, needed two steps later.
+      float SyyC = 1.0f, SyyF = 1.0f;
       {
         float acc[FP_NCH];
 #pragma unroll
@@ -387,19 +472,27 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         float4 xq[6];
 #pragma unroll
         for (int v = 0; v < 6; v++) xq[v] = *reinterpret_cast<const float4 *>(xb + 4 * v);
+        // Beside the 11 multiply-adds of a step ride the two initial energies of find_best_pitch (pitch.cpp:62-63), which
+        // depend on the signal only: SyyC = 1 + sum_{j<240} y_lp4[j]^2 (one term per step) and SyyF = 1 + sum_{j<480} y[j]^2
+        // (two terms per step), their squares lane-distributed (yc: elements j0 + lane; yf0 / yf1: 2 j0 + lane, + 16).
+        float yc = pbuf[2 * l], yf0 = pbuf[l], yf1 = pbuf[16 + l];
 #pragma unroll 1
         for (int j0 = 0; j0 < 240; j0 += 12) {
           float4 xn[6];
           const int jn = j0 + 12 < 240 ? j0 + 12 : j0;       // the last block re-reads itself
+          const float qc = yc * yc, qf0 = yf0 * yf0, qf1 = yf1 * yf1;
 #pragma unroll
           for (int v = 0; v < 6; v++) xn[v] = *reinterpret_cast<const float4 *>(xb + 2 * jn + 4 * v);
-#pragma unroll
-          for (int u = 0; u < 12; u++) {
-            const float xj = (u & 1) ? xq[u >> 1].z : xq[u >> 1].x;      // pbuf[384 + 2 (j0 + u)]
-#pragma unroll
-            for (int c = 0; c < FP_NCH; c++) acc[c] = acc[c] + xj * R[(u + c) % 12];
-            R[u] = yb[2 * (j0 + u + 12)];
-          }
+          yc = pbuf[2 * (jn + l)]; yf0 = pbuf[2 * jn + l]; yf1 = pbuf[2 * jn + 16 + l];
+#define FP_CO_STEP(u) {                                                                         \
+            const float xj = ((u) & 1) ? xq[(u) >> 1].z : xq[(u) >> 1].x;      /* pbuf[384 + 2 (j0 + u)] */ \
+            _Pragma("unroll") for (int c = 0; c < FP_NCH; c++) acc[c] = acc[c] + xj * R[((u) + c) % 12]; \
+            R[u] = yb[2 * (j0 + (u) + 12)];                                                      \
+            SyyC = SyyC + fp_bc<u>(qc);                                                          \
+            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u)>(qf0) : fp_bc<2 * (u) - 16>(qf1));              \
+            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u) + 1>(qf0) : fp_bc<2 * (u) - 15>(qf1)); }
+          FP_REP12(FP_CO_STEP)
+#undef FP_CO_STEP
 #pragma unroll
           for (int v = 0; v < 6; v++) xq[v] = xn[v];
         }
@@ -407,19 +500,22 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         for (int c = 0; c < FP_NCH; c++) xcs[FP_NCH * l + c] = acc[c];
       }
       PN_WAVE_SYNC();
+      FE_MARK(3);   // coarse cross-correlation
       int bp0, bp1;
-      fe_find_best_pitch<240, 147, 2>(xcs, pbuf, sq64, d1, l, bp0, bp1);
+      fp_coarse_best_pitch(xcs, pbuf, l, SyyC, bp0, bp1);
       PN_WAVE_SYNC();
+      FE_MARK(4);   // coarse best-pitch scan
       // fine (2x decimation): only lags within +-2 of 2*best (pitch.cpp:344-361); every other xcorr entry is 0
       int cidx; float cval; bool cact;
       const int dup_lo = 2 * bp0 - 2;
       {
         cidx = (l < 5) ? (2 * bp0 - 2 + l) : (2 * bp1 - 2 + (l - 5));
         cact = l < 10 && cidx >= 0 && cidx < 294;
-        const float sum = fe_chain<480>(pbuf + 384, pbuf + (cact ? cidx : 0), 0.f);
+        const float sum = fp_fine_chain_scan(pbuf + 384, pbuf + (cact ? cidx : 0), pbuf, scr, l, SyyF);
         cval = (-1 > sum) ? -1 : sum;
       }
-      fp_fine_best_pitch(pbuf, sq64, d1, l, gb, cidx, cval, cact, dup_lo, bp0, bp1);
+      FE_MARK(5);   // fine cross-correlation
+      fp_fine_best_pitch(scr, l, gb, cidx, cval, cact, dup_lo, bp0, bp1);
       int offset = 0;
       if (bp0 > 0 && bp0 < 294 - 1) {
         const float a = fp_sparse_at(bp0 - 1, gb, cidx, cval, cact), b = fp_sparse_at(bp0, gb, cidx, cval, cact),
@@ -431,6 +527,7 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
       int pitch_index = PN_PITCH_MAX - (2 * bp0 - offset);       // denoise.cpp:408
       PN_WAVE_SYNC();
 
+      FE_MARK(6);   // fine best-pitch scan + interpolation
       // -- remove_doubling (pitch.cpp:424-527): maxperiod 384, minperiod 30, N 480, x = pbuf+384 -----
       float pg;
       {
@@ -453,57 +550,49 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         }
         float dot1 = 0, dot2 = 0;
         // x = pbuf + 384 sits at an even float of the (even) slice: the parity of x - lag is the parity of the lag
-#if PN_FP_PAIRS
-        fp_chain2_pairs<480>(x, x - lag1, (lag1 & 1) != 0, x - lag2, (lag2 & 1) != 0, dot1, dot2);
-#else
-        fe_chain2<480>(x, x - lag1, x - lag2, dot1, dot2);
-#endif
+        fp_chain2_pairs<480>(x, x - lag1, (lag1 & 1) != 0, x - lag2, (lag2 & 1) != 0, l, dot1, dot2);
+        FE_MARK(7);   // remove_doubling: 29 inner products
         const float xx = __shfl(dot1, gb);
         float xy = __shfl(dot1, gb + 1);
-        // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, group-uniform.  Squares formed lane-parallel,
-        // 64 at a time, into a broadcast scratch; the recurrence reads them 4 per ds_read_b128.  Instead of storing the
-        // 384 clamped values, every lane captures the two it will look up (lane 1 looks up T0 twice).
-        float y1 = xx, y2 = xx;                  // yy_lookup[0] = xx
+        // yy_lookup (pitch.cpp:449-455): strictly sequential running energy, group-uniform: yy += x[-i]^2 - x[N-i]^2.  The
+        // squares are formed lane-parallel, 64 at a time, and stay lane-distributed in registers (fp_bc); the clamp
+        // MAX32(0, yy) of the table does not feed back into the recurrence, so the chain is an add and a subtract per
+        // step; lane u keeps the steps == u (mod 16), the 384 raw values go to LDS once and every lane reads its two.
+        float y1, y2;
         {
-          float *pq = xcs;                       // p[64] | q[64]
+          float *ybuf = scr;                     // the unclamped running energy of i = 1 .. 384 at [i - 1]
           float yy = xx;
+          float an[4], cn[4];
+#define FP_YY_LOAD(blk) do {                                                                      \
+    _Pragma("unroll") for (int w = 0; w < 4; w++) { const int i = 1 + 64 * (blk) + l + L * w; an[w] = x[-i]; cn[w] = x[480 - i]; } \
+  } while (0)
+          FP_YY_LOAD(0);
 #pragma unroll 1
-          for (int blk = 0; blk < 6; blk++) {        // i = 1 + 64*blk + u, u < 64  (384 = 6*64)
+          for (int blk = 0; blk < 6; blk++) {        // i = 1 + 64 blk + 16 w + u  (384 = 6 * 64)
             float pa[4], qa[4];
 #pragma unroll
+            for (int w = 0; w < 4; w++) { pa[w] = an[w] * an[w]; qa[w] = cn[w] * cn[w]; }
+            FP_YY_LOAD(blk < 5 ? blk + 1 : blk);       // next block's operands arrive under this block's chain
+            FP_FENCE();
+#pragma unroll
             for (int w = 0; w < 4; w++) {
-              const int i = 1 + 64 * blk + l + L * w;
-              const float a = x[-i], c = x[480 - i];
-              pa[w] = a * a; qa[w] = c * c;
-            }
-            PN_WAVE_SYNC();
-#pragma unroll
-            for (int w = 0; w < 4; w++) { pq[l + L * w] = pa[w]; pq[64 + l + L * w] = qa[w]; }
-            PN_WAVE_SYNC();
-            const int r1 = lag1 - 1 - 64 * blk, r2 = lag2 - 1 - 64 * blk;
-#pragma unroll
-            for (int h0 = 0; h0 < 16; h0 += 8) {       // operands of 32 steps read before the chain
-              float4 p4[8], q4[8];
-#pragma unroll
-              for (int v = 0; v < 8; v++) {
-                p4[v] = *reinterpret_cast<const float4 *>(pq + 4 * (h0 + v));
-                q4[v] = *reinterpret_cast<const float4 *>(pq + 64 + 4 * (h0 + v));
-              }
-#pragma unroll
-              for (int v = 0; v < 8; v++) {
-                const float pp[4] = {p4[v].x, p4[v].y, p4[v].z, p4[v].w}, qq[4] = {q4[v].x, q4[v].y, q4[v].z, q4[v].w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  yy = yy + pp[e] - qq[e];
-                  const float o = (0 > yy) ? 0 : yy;
-                  y1 = (r1 == 4 * (h0 + v) + e) ? o : y1;
-                  y2 = (r2 == 4 * (h0 + v) + e) ? o : y2;
-                }
-              }
+              const float pw_ = pa[w], qw_ = qa[w];
+              float cw = 0.f;
+#define FP_YY_STEP(u) yy = yy + fp_bc<u>(pw_); yy = yy - fp_bc<u>(qw_); cw = (l == (u)) ? yy : cw;
+              FP_REP16(FP_YY_STEP)
+#undef FP_YY_STEP
+              ybuf[64 * blk + L * w + l] = cw;
             }
           }
+#undef FP_YY_LOAD
+          PN_WAVE_SYNC();
+          // yy_lookup[i] = MAX32(0, yy) for i >= 1, yy_lookup[0] = xx; lane 1 looks up T0 twice
+          const float r1 = ybuf[lag1 > 0 ? lag1 - 1 : 0], r2 = ybuf[lag2 > 0 ? lag2 - 1 : 0];
+          y1 = lag1 > 0 ? ((0 > r1) ? 0 : r1) : xx;
+          y2 = lag2 > 0 ? ((0 > r2) ? 0 : r2) : xx;
         }
         PN_WAVE_SYNC();
+        FE_MARK(8);   // remove_doubling: yy_lookup
         float yy = __shfl(y1, gb + 1);           // yy_lookup[T0]
         float best_xy = xy, best_yy = yy;
         const float g0 = fe_pitch_gain(xy, xx, yy);
@@ -536,11 +625,8 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
         // xcorr[k] = x . (x - (T + k - 1)), k = 0..2 (pitch.cpp:511-512): lane lam holds k = 2 - lam, so that the operands of
         // consecutive lanes are consecutive floats (x[j - Tsel - 1 + lam]) and one row read serves 12 steps
-#if PN_FP_ROWS
         const float xc = fp_chain_rows<480>(x, x - (Tsel + 1), l, 0.f);
-#else
-        const float xc = fe_chain<480>(x, x - (Tsel + 1) + (l < 3 ? l : 2), 0.f);
-#endif
+        FE_MARK(12);  // remove_doubling: decision + the three final inner products
         const float xc0 = __shfl(xc, gb + 2), xc1 = __shfl(xc, gb + 1), xc2 = __shfl(xc, gb);
         int off2;
         if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
@@ -550,6 +636,7 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         pitch_index = 2 * Tsel + off2;
         if (pitch_index < PN_PITCH_MIN) pitch_index = PN_PITCH_MIN;
       }
+      FE_MARK(9);   // remove_doubling: refinement + outputs
       if (l == 0) {
         last_period[s] = pitch_index; last_gain[s] = pg;
         float *f = feat + (size_t)s * PN_FEAT_STRIDE;
