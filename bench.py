@@ -391,6 +391,12 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0):
         for k in range(6):                                   # warm the pipeline (streams, staging buffers, clocks)
             ctx.submit_host_i16(*bufs[k % 3])
         ctx.host_wait()
+        ser = []
+        for k in range(3):                                   # the serial host call, for scale: copy in + the frame + copy out
+            t_s = time.perf_counter()
+            if L.pn_process_host_i16(ctx.h, bufs[k][0], bufs[k][1], None):
+                raise RuntimeError("pn_process_host_i16 failed")
+            ser.append(time.perf_counter() - t_s)
         N = int(seconds * 100)
         period = 0.010
         arrive = np.empty(N); ret = np.empty(N); start = np.empty(N)
@@ -415,6 +421,7 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0):
                "deadline_misses": int((late > 0).sum()), "max_lateness_ms": round(float(max(late.max(), 0.0)) * 1e3, 4),
                "submit_call_ms": percentiles((ret - start) * 1e3), "submit_backlog_ms_max": round(float(backlog.max()) * 1e3, 4),
                "finished_behind_schedule_ms": round((t_end - (t0 + period * N)) * 1e3, 4),
+               "serial_host_call_ms": round(1e3 * min(ser), 3),
                "path": "pn_submit_host_i16 (pinned host buffers, PCIe both ways inside the loop)"}
         out.update(clk.summary())
         return out
