@@ -41,6 +41,25 @@ def test_single_rank_line_has_measured_parity_and_roofline():
     assert abs(r["value"] * 100 - r["frames_per_s"]) < 10
 
 
+def test_paced_real_time_run_through_the_pipelined_host_path():
+    """bench.paced_realtime: frames arrive on the host every 10 ms and go through pn_submit_host_i16 (copy-in / compute /
+    copy-out on three streams, the copy streams on their own priority levels).  A small batch must meet every deadline, the
+    submit call must return in well under a period, and the serial host call (copy + frame + copy) is reported for scale.
+    The process owns other streams when it runs (torch's, a second context's), as bench.py's does."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from percepnet_amd import api, synth, weights
+    model = api.Model(weights.default_blob(1234))
+    side = [torch.cuda.Stream() for _ in range(4)]          # noqa: F841 — streams that compete for HIP's hardware queues
+    other = api.Context(model, 256)
+    r = bench.paced_realtime(api, synth, model, 0, 4096, api.NN_MFMA, seconds=0.6)
+    other.close()
+    assert r["frames"] == 60 and r["streams"] == 4096
+    assert r["deadline_misses"] == 0 and r["submit_call_ms"]["p99"] < 5.0 and r["finished_behind_schedule_ms"] < 10.0
+    assert 0 < r["serial_host_call_ms"] < 10.0
+
+
 def test_split_precision_and_fp16_lines():
     """`--x3` and `--fp16`: the line names the mode, the dtype string says what is computed, the parity numbers are the
     run's own and inside the mode's bound, and the roofline is priced against the fp16 matrix peak (a third of it for the
