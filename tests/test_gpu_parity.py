@@ -707,6 +707,48 @@ def test_extreme_inputs_strict_bit_exact(model, oracle):
         assert np.minimum(d, 65536 - d).max() <= PCM_TOL_LSB, (mode, int(np.minimum(d, 65536 - d).max()))
 
 
+def test_pitch_analysis_on_periodic_signals_bit_exact(model, oracle):
+    """The pitch kernel (pn_dsp_fe_split_p.hip) against the oracle where its decisions are hard: pulse trains and sawtooths
+    at periods across and beyond the pitch range (32 .. 800 samples: below PITCH_MIN, through every `remove_doubling`
+    subharmonic k = 2..15, above PITCH_MAX), two-harmonic mixtures whose fundamental is missing, a slow chirp, period
+    jumps between frames (the continuity terms prev_period / prev_gain), and amplitude steps.  Features (68 = period,
+    69 = correlation), silence flags, taps and PCM must be bit-identical in STRICT mode over 24 frames; the detected
+    periods must cover the range (the test is not vacuous)."""
+    T = 24
+    n = T * 480
+    t = np.arange(n)
+    rows = []
+    for P in list(range(32, 128, 7)) + list(range(128, 800, 23)):
+        rows.append(np.where(t % P == 0, 20000, 0))                                  # pulse train
+        rows.append(((t % P) * (24000.0 / P) - 12000).astype(np.int64))              # sawtooth
+    for P in (96, 150, 233, 377, 610):
+        w = 2 * np.pi / P
+        rows.append((6000 * np.sin(2 * w * t) + 5000 * np.sin(3 * w * t)).astype(np.int64))      # missing fundamental
+        rows.append((9000 * np.sin(w * t) * (1 + 0.5 * np.sign(np.sin(2 * np.pi * t / 4800.0)))).astype(np.int64))   # amplitude steps
+        Pj = np.where((t // 1440) % 2 == 0, P, P + 37)                                # period jumps every 3 frames
+        rows.append(np.where(t % Pj == 0, 18000, 0))
+    rows.append((8000 * np.sin(2 * np.pi * np.cumsum(1.0 / (60 + 700.0 * t / n)))).astype(np.int64))               # chirp 60 -> 760
+    x = np.stack(rows).astype(np.int16)
+    B = x.shape[0]
+    ro, rg, rf, rs = oracle.run_batch(x, threads=8)
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    out = np.zeros_like(ro); gr = np.zeros_like(rg)
+    periods = set()
+    for f in range(T):
+        o, g = ctx.process_i16(x[:, f * 480:(f + 1) * 480])
+        feat, sil = ctx.read_features()
+        assert np.array_equal(feat.view(np.uint32), rf[:, f].view(np.uint32)), (f, np.argwhere(feat.view(np.uint32) != rf[:, f].view(np.uint32))[:4])
+        assert np.array_equal(sil, rs[:, f]), f
+        periods.update(np.round(feat[:, 68] * (768 - 3 * 60)).astype(int).tolist())
+        gr[:, f] = g
+        if f > 0:
+            out[:, (f - 1) * 480:f * 480] = o
+    ctx.close()
+    assert np.array_equal(out, ro)
+    assert np.array_equal(gr.view(np.uint32), rg.view(np.uint32))
+    assert min(periods) <= 70 and max(periods) >= 700 and len(periods) >= 60, (min(periods), max(periods), len(periods))
+
+
 def test_float_api_huge_and_non_finite_inputs(model, oracle):
     """rnnoise_process_frame takes arbitrary floats (the CLI only ever feeds |x| <= 1).  The reference has a defined x86
     behaviour for everything it is fed — samples at 1e4 stay finite all the way (output ~700), at 1e9 the band energies
