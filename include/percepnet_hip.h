@@ -86,7 +86,11 @@ int pn_ctx_reset(pn_ctx *ctx);                       /* zero all stream state, f
 int pn_ctx_reset_streams(pn_ctx *ctx, const int32_t *ids, int n);
 int pn_ctx_n_streams(const pn_ctx *ctx);
 int64_t pn_ctx_frames_done(const pn_ctx *ctx);
-size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state + weights */
+size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state + weights (weights only if this context created their device copy) */
+/* Bytes of the packed weight copy this context reads — its own or one shared with other contexts of the same model content,
+   device and network mode (pn_ctx_describe: weights=own|shared).  A shared copy outlives its creator while any user lives,
+   and is then reported by no context's pn_ctx_device_bytes: add it once per distinct copy when summing a process. */
+size_t pn_ctx_weight_bytes(const pn_ctx *ctx);
 /* Which kernel families this context launches (chosen at creation from its batch size and nn_mode), as a
    NUL-terminated "key=value ..." string, e.g. "nn=mfma_f32 dense=batch gru=batch gru_rb=batch narrow=n16 frontend=split".
    Returns the length written (excluding the NUL) or -1. */
@@ -105,6 +109,16 @@ int pn_ctx_describe(const pn_ctx *ctx, char *buf, size_t buf_bytes);
    outputs consumed after pn_ctx_synchronize or an event on that stream. */
 int pn_process_f32(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr);
 int pn_process_i16(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr);
+/* Per-call ACTIVE SET.  In the reference a stream's state advances only when ITS rnnoise_process_frame is called
+   (src/denoise.cpp:508-547, src/rnnoise.h:60); these calls advance only the n streams listed in ids[] (host array,
+   distinct ids, any order).  Every other stream keeps all of its state — history, look-ahead, pitch memory, synthesis
+   memory, conv FIFOs, GRU states — bit for bit as if the call had not happened for it: its row of d_in is ignored, its rows
+   of d_out and d_gr are left untouched, and when it is listed again it continues exactly like a reference stream that was
+   only fed the frames it received.  (pn_ctx_read_features rows of a skipped stream are undefined for that tick.)
+   n == n_streams is pn_process_*; the cost is paid per SKIPPED stream (two small launches over those rows: ~4 KB saved
+   and ~52 KB of ring entries shifted per skipped stream-tick), nothing is added to an all-active call. */
+int pn_process_f32_active(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr, const int32_t *ids, int n);
+int pn_process_i16_active(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr, const int32_t *ids, int n);
 /* Optional output stage: the reference's envelope post-filter
    (post_filtering, denoise.cpp:216-250), which it only runs on train()'s TEST synthesis (743),
    applied to the gains inside the back-end kernel between the g/r tap and pitch_filter — the same
@@ -167,6 +181,17 @@ int pn_ctx_reset_profile(pn_ctx *ctx);
    2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r, 10 look-ahead spectra ring, 11 comb-filtered
    spectrum, 12 history ring.  Returns bytes copied or -1. */
 long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_bytes);
+/* Launch-refusal hooks (tests).  A network launcher that is asked for a geometry its software pipeline cannot run returns
+   an error WITHOUT launching and the frame fails: pn_process_* / pn_submit_host_* / pn_ctx_compute_rnn_host return -1 with
+   pn_last_error() naming the launcher — never 0 with stale layer outputs.  (The context's stream state is undefined after
+   a failed frame: pn_ctx_reset before reuse.)
+   pn_debug_check_launch runs the launchers' geometry predicates without a GPU: kind 0 dense on the fp32 MFMA kernels,
+   1 dense / 2 GRU (n_out neurons) on the shadow-operand kernels, 3 narrow dense on 16x16x4 tiles; n_panels panels of
+   `width` columns.  0 = accepted, -1 = refused (pn_last_error()).
+   pn_ctx_debug_inject_launch_failure(ctx, 1) makes every following frame of a non-STRICT context ask the fc layer's
+   launcher for a refused geometry. */
+int pn_debug_check_launch(int kind, int n_panels, int width, int n_out);
+int pn_ctx_debug_inject_launch_failure(pn_ctx *ctx, int enable);
 
 /* ---- batched training-feature generator ----------------------------------- */
 /* The reference's `percepNet <speech> <noisy> <count> <output>` binary (train(), denoise.cpp:603-787,

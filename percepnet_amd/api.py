@@ -55,9 +55,15 @@ def load_library():
     L.pn_ctx_device_bytes.restype = ctypes.c_size_t
     L.pn_ctx_device_bytes.argtypes = [_vp]
     L.pn_ctx_describe.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
+    L.pn_ctx_weight_bytes.restype = ctypes.c_size_t
+    L.pn_ctx_weight_bytes.argtypes = [_vp]
     for name in ("pn_process_f32", "pn_process_i16", "pn_process_host_f32", "pn_process_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
+    for name in ("pn_process_f32_active", "pn_process_i16_active"):
+        getattr(L, name).argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]
+    L.pn_debug_check_launch.argtypes = [ctypes.c_int] * 4
+    L.pn_ctx_debug_inject_launch_failure.argtypes = [_vp, ctypes.c_int]
     for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_host_wait.argtypes = [_vp]
@@ -162,6 +168,9 @@ class Context:
     def device_bytes(self):
         return self.L.pn_ctx_device_bytes(self.h)
 
+    def weight_bytes(self):
+        return self.L.pn_ctx_weight_bytes(self.h)
+
     def describe(self):
         """{"nn": ..., "dense": "small"|"batch", "gru": ..., "gru_rb": ..., "frontend": ...}: the kernel families in use."""
         buf = ctypes.create_string_buffer(256)
@@ -175,6 +184,19 @@ class Context:
 
     def process_f32_dev(self, d_in, d_out, d_gr=None):
         self._chk(self.L.pn_process_f32(self.h, d_in, d_out, d_gr))
+
+    def process_i16_active_dev(self, d_in, d_out, d_gr, ids):
+        """One frame for the streams `ids` only; every other stream keeps all of its state and its output rows
+        (include/percepnet_hip.h pn_process_i16_active; reference contract: src/denoise.cpp:508-547, one call per stream)."""
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).ravel())
+        self._chk(self.L.pn_process_i16_active(self.h, d_in, d_out, d_gr, a.ctypes.data, int(a.size)))
+
+    def process_f32_active_dev(self, d_in, d_out, d_gr, ids):
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).ravel())
+        self._chk(self.L.pn_process_f32_active(self.h, d_in, d_out, d_gr, a.ctypes.data, int(a.size)))
+
+    def debug_inject_launch_failure(self, enable):
+        self._chk(self.L.pn_ctx_debug_inject_launch_failure(self.h, int(bool(enable))))
 
     # pipelined host-buffer entry points (raw host pointers; the buffers should be pinned and must outlive delivery)
     def submit_host_i16(self, h_in, h_out, h_gr=None):

@@ -37,10 +37,23 @@ struct SharedWeights {
   DevLayer L[PN_NLAYERS];
   std::vector<void *> allocs;
   size_t bytes = 0;
+  bool cached = false;             // in g_weights (a copy built after a hash collision is private to its context)
+  std::vector<float> host;         // the model arrays this copy was built from: a cache hit is compared byte for byte
+  PnLayerHost desc[PN_NLAYERS];    // ... and layer descriptor for layer descriptor (activation, reset_after)
 };
-typedef std::tuple<uint64_t, int, int, int> WeightsKey;      // content hash, device, nn_mode, narrow layers packed for the n16 kernel
-static std::mutex g_weights_mu;
+// two independent content hashes + array length, device, nn_mode, narrow layers packed for the n16 kernel.  The hashes are
+// not cryptographic (a PNW1 file can be crafted to collide): the key only FINDS a candidate, the byte comparison decides.
+typedef std::tuple<uint64_t, uint64_t, size_t, int, int, int> WeightsKey;
+static std::mutex g_weights_mu;                              // guards g_weights and every refs counter
+static std::mutex g_weights_build_mu[16];                    // per device (mod 16): uploads and re-packs of DIFFERENT devices run
+                                                             // side by side (percepnet_run --devices creates its contexts from one thread per device)
 static std::map<WeightsKey, SharedWeights *> g_weights;
+static bool same_model(const SharedWeights *w, const pn_model *m) {
+  if (w->host.size() != m->n_floats || memcmp(w->host.data(), m->storage, m->n_floats * 4) != 0) return false;
+  for (int li = 0; li < PN_NLAYERS; li++)
+    if (w->desc[li].act != m->L[li].act || w->desc[li].reset_after != m->L[li].reset_after) return false;
+  return true;
+}
 
 struct pn_ctx {
   int device, B, nn_mode;
@@ -63,6 +76,14 @@ struct pn_ctx {
   int *d_ids = NULL; int ids_cap = 0;
   struct IdSlot { int *h = NULL; hipEvent_t ev = nullptr; } id_slot[4];
   unsigned id_calls = 0;
+  // pn_process_*_active: inactive-row list on the device (+ its ring of pinned host copies) and the save area of the
+  // in-place state of those rows, grown on demand
+  struct Active {
+    int *d_ids = NULL; int cap = 0;
+    pn_ctx::IdSlot slot[4]; unsigned calls = 0;
+    float *save_synth = NULL, *save_gr = NULL, *save_gain = NULL; uint32_t *save_out = NULL; int *save_period = NULL;
+    std::vector<uint8_t> mark; std::vector<int32_t> inactive;
+  } act;
   PnTables *tables; float *tansig;
   float *hist, *synth, *last_gain, *feat, *c1ring, *c2ring, *c2out, *gru[4], *rb, *gr, *io_in, *io_out;
   // fp16-operand variant only: shadow copies (2 bytes per element, same indexing) of the buffers the GEMMs read
@@ -72,6 +93,7 @@ struct pn_ctx {
   bool postfilter = false;         // optional envelope post-filter in the back end (pn_ctx_set_postfilter)
   bool x3_sat = false;             // PERCEPNET_X3_SATCOUNT=1 (shadow-operand modes): count operand values clamped to the fp16 range
   int dsp_grid_cap = 0;            // > 0 only in the DSP self-test's temporary context: its DSP launches use that many blocks
+  bool inject_bad_launch = false;  // pn_ctx_debug_inject_launch_failure (tests): the next frames hand fc a geometry its launcher refuses
   int *last_period, *silence;
   std::vector<void *> allocs;
   bool profiling;
@@ -196,11 +218,12 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   for (void *p : c->allocs) hipFree(p);
   for (auto &sl : c->id_slot) { if (sl.h) hipHostFree(sl.h); if (sl.ev) hipEventDestroy(sl.ev); }
+  for (auto &sl : c->act.slot) { if (sl.h) hipHostFree(sl.h); if (sl.ev) hipEventDestroy(sl.ev); }
   if (c->weights) {
     std::lock_guard<std::mutex> lk(g_weights_mu);
     if (--c->weights->refs == 0) {
       for (void *p : c->weights->allocs) hipFree(p);
-      g_weights.erase(c->weights_key);
+      if (c->weights->cached) g_weights.erase(c->weights_key);
       delete c->weights;
     }
   }
@@ -336,17 +359,29 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   if (zero_state(c)) goto fail;
   for (int li = 0; li < PN_NLAYERS; li++) { c->geom[li] = model->L[li]; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL; }
   {   // the device copy of the weights: shared with every other context of this model content on this device in this mode
-    const bool n16 = (nn_mode == PN_NN_MFMA) && (force_n16 >= 0 ? force_n16 != 0 : n16_rows_ok(n_streams));
-    c->weights_key = std::make_tuple(model->content_hash, device, nn_mode, n16 ? 1 : 0);
-    std::lock_guard<std::mutex> lk(g_weights_mu);
-    auto it = g_weights.find(c->weights_key);
-    if (it != g_weights.end()) { c->weights = it->second; c->weights_were_cached = true; }
-    else {
-      c->weights = build_weights(c, model, nn_mode, n16);
-      if (!c->weights) goto fail;
-      g_weights[c->weights_key] = c->weights;
+    // narrow layers on the 16x16x4 kernel at small batches in every MFMA mode (in the shadow-operand modes that is fc_rb; fc_gb runs on their own kernels)
+    const bool n16 = (nn_mode != PN_NN_STRICT) && (force_n16 >= 0 ? force_n16 != 0 : n16_rows_ok(n_streams));
+    c->weights_key = std::make_tuple(model->content_hash, model->content_hash2, model->n_floats, device, nn_mode, n16 ? 1 : 0);
+    std::lock_guard<std::mutex> build_lk(g_weights_build_mu[device & 15]);   // one build per device at a time; the map lock is never held across a build
+    SharedWeights *hit = NULL; bool collision = false;
+    {
+      std::lock_guard<std::mutex> lk(g_weights_mu);
+      auto it = g_weights.find(c->weights_key);
+      if (it != g_weights.end()) {
+        if (same_model(it->second, model)) { hit = it->second; hit->refs++; }
+        else collision = true;                           // same key, different bytes: this context gets a private copy
+      }
     }
-    c->weights->refs++;
+    if (hit) { c->weights = hit; c->weights_were_cached = true; }
+    else {
+      SharedWeights *w = build_weights(c, model, nn_mode, n16);
+      if (!w) goto fail;
+      w->host.assign(model->storage, model->storage + model->n_floats);
+      memcpy(w->desc, model->L, sizeof(w->desc));
+      w->refs = 1; w->cached = !collision;
+      c->weights = w;
+      if (!collision) { std::lock_guard<std::mutex> lk(g_weights_mu); g_weights[c->weights_key] = w; }
+    }
     memcpy(c->L, c->weights->L, sizeof(c->L));
   }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { pn_set_error("initial upload failed"); goto fail; }
@@ -427,6 +462,9 @@ extern "C" int64_t pn_ctx_frames_done(const pn_ctx *c) { return c ? c->t : -1; }
 // state (+ tables) of this context, plus the weights if this context created their device copy (a context that found them
 // in the cache adds nothing: the copy is shared)
 extern "C" size_t pn_ctx_device_bytes(const pn_ctx *c) { return c ? c->bytes + ((c->weights && !c->weights_were_cached) ? c->weights->bytes : 0) : 0; }
+// bytes of the packed weight copy this context reads, whoever created it: a process's footprint is the sum of
+// pn_ctx_device_bytes over its contexts plus every DISTINCT shared copy that no live context reports as its own
+extern "C" size_t pn_ctx_weight_bytes(const pn_ctx *c) { return (c && c->weights) ? c->weights->bytes : 0; }
 extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   if (!c || !buf || !n) return -1;
   const char *nn = c->nn_mode == PN_NN_STRICT ? "strict" : (c->nn_mode == PN_NN_MFMA_F16 ? "mfma_f16" : (c->nn_mode == PN_NN_MFMA_X3 ? "mfma_x3" : "mfma_f32"));
@@ -524,37 +562,41 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
   return H;
 }
 
-static void launch_rnn(pn_ctx *c) {
+// Returns 0, or -1 when a launcher refused its geometry (pn_set_error names it): nothing after the refused layer is
+// launched and the caller fails the frame.
+static int launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
   // x3: the layers that run on the fp16 matrix cores from operand shadows — split precision (hi + lo planes) or fp16 operands (hi only)
   const bool x3 = c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16;
   const int np = c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1;
   hipStream_t st = c->stream; const float *tab = c->tansig;
+  int rc = 0;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
   float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128;
   float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512;
   { Scope sc(c, KF_FC);
     PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
-    pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
+    if (c->inject_bad_launch && !strict) A.width[0] = 96;   // test hook: three K-tiles, which every MFMA dense launcher refuses
+    rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
     if (x3) pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp, np); }   // fc runs in fp32 (70 inputs); its output enters the shadow-operand layers
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B, c->x3_rg, np);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B, c->small); }
+    if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, (int)B, c->x3_rg, np);
+    else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, (int)B, c->small); }
   { Scope sc(c, KF_CONV2);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B, c->x3_rg, np);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B, c->small); }
+    if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, c->c2outH, 16, (int)B, c->x3_rg, np);
+    else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c->c2out, 512, (int)B, c->small); }
   const float *x = c->c2out;
-  for (int i = 0; i < 4; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
+  for (int i = 0; i < 4 && !rc; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
     Scope sc(c, KF_GRU512);
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512;
     PnSegs X = seg1(x, 512, 512);
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B, c->x3_rg, np);
-    else pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
+    if (x3) rc |= pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), (int)B, c->x3_rg, np);
+    else rc |= pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, (int)B, c->small_gru);
     x = hn;
   }
   const float *g1 = c->gru[0] + (size_t)nxt * Bp * 512, *g2 = c->gru[1] + (size_t)nxt * Bp * 512,
@@ -564,19 +606,20 @@ static void launch_rnn(pn_ctx *c) {
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c->c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
-    if (x3) pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B, c->x3_rg, np);
-    else pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
+    if (x3) rc |= pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), (int)B, c->x3_rg, np);
+    else rc |= pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, (int)B, c->small); }   // gru_rb (1024->128) crosses over with the dense layers
   { Scope sc(c, KF_FC_GB);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c->c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
-    if (x3) pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B, c->x3_rg, np);
-    else if (c->L[PN_L_FC_GB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
+    if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, NULL, 0, (int)B, c->x3_rg, np);
+    else if (c->L[PN_L_FC_GB].wq) rc |= pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B);
+    else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, c->gr, 68, (int)B, c->small); }
   { Scope sc(c, KF_FC_RB);
     PnSegs A = seg1(rbn, 128, 128);
-    if (c->L[PN_L_FC_RB].wq) pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
-    else pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B, c->small); }
+    if (c->L[PN_L_FC_RB].wq) rc |= pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B);
+    else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, c->gr + 34, 68, (int)B, c->small); }
+  return rc ? -1 : 0;
 }
 
 // Known-answer self-test of the MFMA network kernels (PERCEPNET_SELFTEST=0 skips it).
@@ -623,7 +666,7 @@ static pn_model *selftest_model() {
 static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const int n16 = c->L[PN_L_FC_GB].wq != NULL;           // narrow layers on the 16x16x4 kernel (small batches) or on the batch GEMM
+  const int n16 = c->L[PN_L_FC_RB].wq != NULL;           // narrow layers on the 16x16x4 kernel (small batches; fc_rb in every MFMA mode, fc_gb in the fp32 one) or on the batch GEMM
   const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : 0, n16);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
@@ -761,7 +804,7 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
     (c->fe_mode == FE_MONO_G2 ? pn_launch_frontend_g2 : pn_launch_frontend)(c->stream, c->tables, c->B, c->t, d_in, is_i16, PN_FRAME, 1.f / 32768.f,
         c->hist, c->yring, c->eyring, c->Ps, c->feat, c->silence, c->last_period, c->last_gain, nullptr, c->dsp_grid_cap);
   }
-  launch_rnn(c);
+  if (launch_rnn(c)) return -1;                        // a refused launch fails the frame (pn_last_error says which layer)
   { Scope sc(c, KF_BACKEND);
     // X(t) == the look-ahead spectrum of frame t-5 (pn_dsp_fe.hip): ring slot (t+1)%6
     const size_t slot = (size_t)((c->t + 1) % 6);
@@ -772,6 +815,15 @@ static int process_dev(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, in
   PN_HIP_CHECK(hipGetLastError());
   c->t++; c->tn++;
   if (c->events.size() >= 4096 && flush_events(c)) return -1;   // profiling left on: bound the pending events
+  return 0;
+}
+
+// Test hook (tests/test_gpu_lifecycle.py): while enabled, every frame asks the fc layer's launcher for a geometry it refuses —
+// pn_process_* / pn_submit_host_* / pn_ctx_compute_rnn_host must then return -1 with pn_last_error() naming the launcher,
+// never 0 with stale outputs (STRICT contexts have no such refusal: their kernels take any geometry).
+extern "C" int pn_ctx_debug_inject_launch_failure(pn_ctx *c, int enable) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  c->inject_bad_launch = enable != 0;
   return 0;
 }
 
@@ -790,6 +842,66 @@ extern "C" int pn_process_i16_multi(pn_ctx *c, const int16_t *d_in, int16_t *d_o
     if (process_dev(c, d_in + f * fs, d_out + f * fs, d_gr ? d_gr + (size_t)f * c->B * 68 : NULL, 1)) return -1;
   return 0;
 }
+
+// ---- per-call active set (pn_active.hip) -----------------------------------------------------------------------------
+// ids[0..n): the streams that receive a frame in this call (distinct, any order).  Every other stream keeps ALL of its
+// state — as if its rnnoise_process_frame had not been called (denoise.cpp:508-547) — and its rows of d_out / d_gr are
+// left as they were; its row of d_in is ignored.  n == n_streams is exactly pn_process_*.
+static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16, const int32_t *ids, int n) {
+  if (!c || !d_in || !d_out || n < 0 || (n > 0 && !ids)) { pn_set_error("bad argument"); return -1; }
+  const int B = c->B;
+  if (n > B) { pn_set_error("%d active streams in a context of %d", n, B); return -1; }
+  pn_ctx::Active &A = c->act;
+  A.mark.assign((size_t)B, 0);
+  for (int i = 0; i < n; i++) {
+    if (ids[i] < 0 || ids[i] >= B) { pn_set_error("stream id %d out of range [0, %d)", ids[i], B); return -1; }
+    if (A.mark[ids[i]]) { pn_set_error("stream id %d listed twice", ids[i]); return -1; }
+    A.mark[ids[i]] = 1;
+  }
+  if (n == B) return process_dev(c, d_in, d_out, d_gr, is_i16);
+  A.inactive.clear();
+  for (int s = 0; s < B; s++) if (!A.mark[s]) A.inactive.push_back(s);
+  const int ni = (int)A.inactive.size();
+  PN_ON_DEVICE(c);
+  if (A.cap < ni) {
+    // (the old, smaller buffers stay in allocs until destroy: kernels of an earlier call may still be using them)
+    int cap = 1024; while (cap < ni) cap *= 2; if (cap > B) cap = B;
+    if (dev_alloc(c, (void **)&A.d_ids, (size_t)cap * 4, false) || dev_alloc(c, (void **)&A.save_synth, (size_t)cap * PN_FRAME * 4, false) ||
+        dev_alloc(c, (void **)&A.save_out, (size_t)cap * PN_FRAME * 4, false) || dev_alloc(c, (void **)&A.save_gr, (size_t)cap * 68 * 4, false) ||
+        dev_alloc(c, (void **)&A.save_period, (size_t)cap * 4, false) || dev_alloc(c, (void **)&A.save_gain, (size_t)cap * 4, false)) return -1;
+    for (auto &sl : A.slot) {
+      if (sl.ev) PN_HIP_CHECK(hipEventSynchronize(sl.ev));
+      if (sl.h) hipHostFree(sl.h);
+      sl.h = NULL;
+      PN_HIP_CHECK(hipHostMalloc((void **)&sl.h, (size_t)cap * sizeof(int), hipHostMallocDefault));
+      if (!sl.ev) PN_HIP_CHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    A.cap = cap;
+  }
+  {
+    pn_ctx::IdSlot &sl = A.slot[A.calls++ & 3];
+    PN_HIP_CHECK(hipEventSynchronize(sl.ev));             // the copy issued from this slot four calls ago has executed
+    memcpy(sl.h, A.inactive.data(), (size_t)ni * sizeof(int));
+    PN_HIP_CHECK(hipMemcpyAsync(A.d_ids, sl.h, (size_t)ni * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PN_HIP_CHECK(hipEventRecord(sl.ev, c->stream));
+  }
+  PnActiveArgs a; memset(&a, 0, sizeof(a));
+  a.ids = A.d_ids; a.synth = c->synth; a.last_period = c->last_period; a.last_gain = c->last_gain;
+  a.out = d_out; a.out_row_words = is_i16 ? PN_FRAME / 2 : PN_FRAME; a.d_gr = d_gr;
+  a.save_synth = A.save_synth; a.save_out = A.save_out; a.save_gr = A.save_gr; a.save_period = A.save_period; a.save_gain = A.save_gain;
+  a.hist = c->hist; a.yring = c->yring; a.eyring = c->eyring; a.c1ring = c->c1ring; a.c2ring = c->c2ring; a.rb = c->rb;
+  for (int i = 0; i < 4; i++) { a.gru[i] = c->gru[i]; a.gruH[i] = (uint4 *)c->gruH[i]; }
+  a.c1ringH = (uint4 *)c->c1ringH; a.c2ringH = (uint4 *)c->c2ringH; a.rbH = (uint4 *)c->rbH;
+  a.np = c->c1ringH ? (int)shadow_halfs_per_element(c) : 0;
+  a.B = B; a.Bp = (long long)c->Bp; a.t = c->t; a.tn = c->tn;
+  pn_launch_inactive_save(c->stream, a, ni);
+  if (process_dev(c, d_in, d_out, d_gr, is_i16)) return -1;
+  pn_launch_inactive_fixup(c->stream, a, ni);           // a.t / a.tn: the counters the frame above ran with
+  PN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int pn_process_f32_active(pn_ctx *c, const float *d_in, float *d_out, float *d_gr, const int32_t *ids, int n) { return process_active(c, d_in, d_out, d_gr, 0, ids, n); }
+extern "C" int pn_process_i16_active(pn_ctx *c, const int16_t *d_in, int16_t *d_out, float *d_gr, const int32_t *ids, int n) { return process_active(c, d_in, d_out, d_gr, 1, ids, n); }
 
 static int process_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
   if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
@@ -906,7 +1018,7 @@ extern "C" int pn_ctx_compute_rnn_host(pn_ctx *c, const float *h_feat, float *h_
   PN_ON_DEVICE(c);
   if (pipe_drain(c)) return -1;                      // frames in flight on the pipelined path own feat/gr
   PN_HIP_CHECK(hipMemcpy2DAsync(c->feat, PN_FEAT_STRIDE * 4, h_feat, PN_NFEAT * 4, PN_NFEAT * 4, c->B, hipMemcpyHostToDevice, c->stream));
-  launch_rnn(c);
+  if (launch_rnn(c)) return -1;
   PN_HIP_CHECK(hipMemcpyAsync(h_gr, c->gr, (size_t)c->B * 68 * 4, hipMemcpyDeviceToHost, c->stream));
   PN_HIP_CHECK(hipStreamSynchronize(c->stream));
   PN_HIP_CHECK(hipGetLastError());

@@ -33,6 +33,12 @@
 #define FP_SPB 16                       // streams per block (4 waves)
 #define FP_THREADS 256
 #define FP_NCH 11                       // coarse lags per lane (lane l owns lags 11 l .. 11 l + 10; 16 * 11 >= 147)
+#ifndef PN_FP_DS_DPP
+#define PN_FP_DS_DPP 1                   // pitch_downsample: x[4m - 1] from the neighbouring lane (row rotate) instead of a scalar load
+#endif
+#ifndef PN_FP_COARSE_PK
+#define PN_FP_COARSE_PK 1                // coarse cross-correlation on packed f32 instructions (0: the scalar round-4 loop)
+#endif
 
 // per-stream LDS slice, in floats
 #define FP_PBUF 0                       // [0,864)     decimated signal, whitened in place
@@ -325,6 +331,8 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
   __shared__ __attribute__((aligned(16))) float SH[FP_SPB * FP_SLICE];
   const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid >> 6;
   const int sub = lane / L, l = lane % L, gb = sub * L;
+  // (slices in the order 0, 2, 1, 3 — the two streams of a 32-lane LDS group 32 banks apart, good for 8-byte runs — was
+  // measured: 0.611 vs 0.577 ms; the 4-byte reads bank mod 32 and want the 16-bank offset this order gives them)
   const int slice0 = (wave * G + sub) * FP_SLICE;
   const int base_slot0 = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
 
@@ -349,6 +357,11 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
 #endif
       float *pbuf = buf + FP_PBUF, *raw = buf + FP_PBUF, *scr = buf + FP_SCR, *xcs = buf + FP_SCR;
       // -- pitch_downsample (pitch.cpp:148-216) of pitch_buf == comb_buf[1632,3360): outputs 2m, 2m+1 need x[4m-1 .. 4m+3]
+#if PN_FP_DS_DPP
+      // x[4m - 1] is the last sample of quad m - 1, which the previous lane of the row holds (lane 0: lane 15 of the
+      // previous batch of 16 quads): a row rotate inside the add instead of a second, scalar global load per quad
+      float wprev = 0.f;                                   // .w of the quads of the previous batch (carried across halves)
+#endif
 #pragma unroll 1
       for (int half = 0; half < 2; half++) {
         constexpr int NM = 14;                             // 2 x 14 x 16 = 448 >= 432 pairs
@@ -357,8 +370,18 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         for (int it = 0; it < NM; it++) {
           const int mm = l + L * (half * NM + it), m = mm < 432 ? mm : 0;
           dv[it] = *reinterpret_cast<const float4 *>(h + fe_ring(1632 + 4 * m, base_slot));
+#if !PN_FP_DS_DPP
           dm1[it] = h[fe_ring(1632 + (m > 0 ? 4 * m - 1 : 0), base_slot)];
+#endif
         }
+#if PN_FP_DS_DPP
+#pragma unroll
+        for (int it = 0; it < NM; it++) {
+          const float z = (l == L - 1) ? wprev : dv[it].w;   // lane 15 passes the previous batch's last sample on to lane 0
+          dm1[it] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, z), 0x121, 0xf, 0xf, true));   // row_ror:1: lane i <- lane i - 1 (mod 16)
+          wprev = dv[it].w;
+        }
+#endif
 #pragma unroll
         for (int it = 0; it < NM; it++) {
           const int m = l + L * (half * NM + it);
@@ -460,6 +483,97 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
       // Lane l owns the 11 consecutive lags 11 l + c.  Twelve registers hold y_lp4[11 l + e] for e = j .. j+11 (register
       // e mod 12): step j uses e = j .. j+10 and then refills the register of e = j with e = j + 12, needed two steps later.
       float SyyC = 1.0f, SyyF = 1.0f;
+#if PN_FP_COARSE_PK
+      // Packed form (round 5).  The 11 chains of a lane run as five v_pk_mul_f32 / v_pk_add_f32 pairs (lags c and c + 5,
+      // c = 0..4) and one scalar chain (lag 10): 12 VALU instructions per step instead of 22 — each chain is still the
+      // reference's sequence of one rounded multiply and one rounded add per j (the packed instructions round each half
+      // like v_mul_f32 / v_add_f32; -ffp-contract=off keeps them unfused).  The sliding window holds PAIRS
+      // W[e] = (y_lp4[11 l + e], y_lp4[11 l + e + 5]), e = j .. j + 11 in a ring of 12 register pairs (pair e mod 12):
+      // step j multiplies W[j + c] by x_lp4[j] for c = 0..4, the scalar chain takes W[j + 5].y, and the pair of e = j is
+      // then refilled with e = j + 12, first needed seven steps later.  A pair is ONE ds_read2_b32 (two dwords ten floats
+      // apart).  x_lp4[j] = pbuf[384 + 2 j] is group-uniform: pair v of an operand set holds steps 2 v and 2 v + 1 (one
+      // ds_read2_b32) and the multiply broadcasts the half it needs through op_sel.
+      // Every LDS read of this loop is issued from inline assembly: written in C++ the compiler recognises that
+      // W[e].y == W[e + 5].x, loads each element once and rebuilds the pairs with ~4 v_mov per step, and it only folds the
+      // broadcast of a LOW half.  Assembly loads are invisible to the compiler's s_waitcnt pass, so the loop waits itself,
+      // every third step, with lgkmcnt(4) — LDS returns in order and at most the four most recent reads may still be in
+      // flight: a ring pair is requested >= 5 reads before the wait that releases it, a trip's operand set a whole trip
+      // (20 reads) before — in a statement that takes what it releases as operands, which keeps every first use behind
+      // the wait.  Everything is drained (lgkmcnt(0)) before any of these registers can be given to something else.
+      {
+        typedef float fp_v2 __attribute__((ext_vector_type(2)));
+        fp_v2 accp[5]; float acc10 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; c++) accp[c] = fp_v2{0.f, 0.f};
+        const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)pbuf;   // LDS byte address of the slice
+        const unsigned ya = pa + 8 * (FP_NCH * l);        // y_lp4[11 l] = pbuf[2 (11 l)]
+        const unsigned xa0 = pa + 4 * 384;                // x_lp4[0]
+        const unsigned ca = pa + 8 * l, fa = pa + 4 * l;  // the energies' lane-distributed operands: pbuf[2 (j + l)], pbuf[2 j + l]
+        fp_v2 W[12], xa[6], xc[6], yf; float yc;
+#define FP_PK_LOAD(u, e) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(W[u]) : "v"(yaj), "n"(2 * (e)), "n"(2 * (e) + 10))
+        // operand set xs_ <- steps jn .. jn + 11, energy operands <- the squares the trip after next adds
+#define FP_PK_OPERANDS(xs_, jn_) do { const unsigned xj_ = xa0 + 8 * (jn_), cj_ = ca + 8 * (jn_), fj_ = fa + 8 * (jn_); \
+          asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:2" : "=&v"(xs_[0]) : "v"(xj_));      \
+          asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:6" : "=&v"(xs_[1]) : "v"(xj_));      \
+          asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:10" : "=&v"(xs_[2]) : "v"(xj_));     \
+          asm volatile("ds_read2_b32 %0, %1 offset0:12 offset1:14" : "=&v"(xs_[3]) : "v"(xj_));    \
+          asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:18" : "=&v"(xs_[4]) : "v"(xj_));    \
+          asm volatile("ds_read2_b32 %0, %1 offset0:20 offset1:22" : "=&v"(xs_[5]) : "v"(xj_));    \
+          asm volatile("ds_read_b32 %0, %1" : "=&v"(yc) : "v"(cj_));                               \
+          asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:16" : "=&v"(yf) : "v"(fj_)); } while (0)
+#define FP_PK_TIE_SET(xs_) "+v"(xs_[0]), "+v"(xs_[1]), "+v"(xs_[2]), "+v"(xs_[3]), "+v"(xs_[4]), "+v"(xs_[5])
+        {
+          const unsigned yaj = ya;
+          FP_PK_LOAD(0, 0); FP_PK_LOAD(1, 1); FP_PK_LOAD(2, 2); FP_PK_LOAD(3, 3); FP_PK_LOAD(4, 4); FP_PK_LOAD(5, 5);
+          FP_PK_LOAD(6, 6); FP_PK_LOAD(7, 7); FP_PK_LOAD(8, 8); FP_PK_LOAD(9, 9); FP_PK_LOAD(10, 10); FP_PK_LOAD(11, 11);
+          FP_PK_OPERANDS(xa, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]), "+v"(W[6]), "+v"(W[7]));
+        }
+        // the energies stay scalar: paired by the SLP vectoriser their DPP operands would be materialised by a v_mov each
+#define FP_CO_ENERGY(u) {                                                                        \
+            SyyC = SyyC + fp_bc<u>(qc); asm("" : "+v"(SyyC));                                     \
+            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u)>(qf0) : fp_bc<2 * (u) - 16>(qf1)); asm("" : "+v"(SyyF)); \
+            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u) + 1>(qf0) : fp_bc<2 * (u) - 15>(qf1)); asm("" : "+v"(SyyF)); }
+#define FP_CO_WAIT(u) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(W[((u) + 5) % 12]), "+v"(W[((u) + 6) % 12]), "+v"(W[((u) + 7) % 12]))
+#define FP_CO_STEP(u) {                                                                         \
+            if ((u) % 3 == 0 && (u)) FP_CO_WAIT(u);       /* releases the pairs the next three steps start to use */ \
+            _Pragma("unroll") for (int c = 0; c < 5; c++) {                                       \
+              fp_v2 pr;                                                                          \
+              if ((u) & 1) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(pr) : "v"(xq_[(u) >> 1]), "v"(W[((u) + c) % 12])); \
+              else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(pr) : "v"(xq_[(u) >> 1]), "v"(W[((u) + c) % 12])); \
+              accp[c] = accp[c] + pr; }                                                          \
+            { float p10 = (((u) & 1) ? xq_[(u) >> 1].y : xq_[(u) >> 1].x) * W[((u) + 5) % 12].y; asm("" : "+v"(p10)); acc10 = acc10 + p10; } \
+            FP_PK_LOAD(u, (u) + 12);                                                             \
+            FP_CO_ENERGY(u) }
+        // 12 steps j0_ .. j0_ + 11 on operand set xcur_ while the operands of the trip after (steps jn_ ..) arrive in xn_.
+        // The trip's first wait also releases its own operand set and energy operands (requested one trip ago).
+#define FP_CO_TRIP(xcur_, xn_, j0_, jn_) {                                                        \
+          fp_v2 (&xq_)[6] = xcur_;                                                                  \
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(W[5]), "+v"(W[6]), "+v"(W[7]), FP_PK_TIE_SET(xcur_), "+v"(yc), "+v"(yf)); \
+          const float qc = yc * yc, qf0 = yf.x * yf.x, qf1 = yf.y * yf.y;                           \
+          FP_PK_OPERANDS(xn_, jn_);                                                                 \
+          const unsigned yaj = ya + 8 * (j0_);                 /* byte address of y_lp4[11 l + j0] */ \
+          FP_REP12(FP_CO_STEP) }
+#pragma unroll 1
+        for (int j0 = 0; j0 < 240; j0 += 24) {
+          FP_CO_TRIP(xa, xc, j0, j0 + 12)
+          const int jn = j0 + 24 < 240 ? j0 + 24 : j0;       // the last trip re-reads a block it does not use
+          FP_CO_TRIP(xc, xa, j0 + 12, jn)
+        }
+#undef FP_CO_TRIP
+#undef FP_CO_STEP
+#undef FP_CO_WAIT
+#undef FP_CO_ENERGY
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]),
+                     "+v"(W[6]), "+v"(W[7]), "+v"(W[8]), "+v"(W[9]), "+v"(W[10]), "+v"(W[11]), FP_PK_TIE_SET(xa), FP_PK_TIE_SET(xc), "+v"(yc), "+v"(yf));
+#undef FP_PK_LOAD
+#undef FP_PK_OPERANDS
+#undef FP_PK_TIE_SET
+#pragma unroll
+        for (int c = 0; c < 5; c++) { xcs[FP_NCH * l + c] = accp[c].x; xcs[FP_NCH * l + c + 5] = accp[c].y; }
+        xcs[FP_NCH * l + 10] = acc10;
+      }
+#else
       {
         float acc[FP_NCH];
 #pragma unroll
@@ -499,6 +613,7 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
 #pragma unroll
         for (int c = 0; c < FP_NCH; c++) xcs[FP_NCH * l + c] = acc[c];
       }
+#endif
       PN_WAVE_SYNC();
       FE_MARK(3);   // coarse cross-correlation
       int bp0, bp1;

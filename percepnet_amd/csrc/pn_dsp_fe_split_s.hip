@@ -40,6 +40,12 @@
 #ifndef PN_FS_WAVES_IN
 #define PN_FS_WAVES_IN 4                // waves per SIMD the register budget of spec_in is cut for (4: 128 registers)
 #endif
+#ifndef PN_FS_COMB_TAP_MAJOR
+#define PN_FS_COMB_TAP_MAJOR 1
+#endif
+#ifndef PN_FS_COMB_SETS
+#define PN_FS_COMB_SETS 3               // register sets of the comb filter's tap loads (one set = the four dwordx4 of a tap)
+#endif
 #ifndef PN_FS_WAVES_OUT
 #define PN_FS_WAVES_OUT 3               // spec_out (28 comb-tap loads + the X spectrum on top): 168 registers, three 4-wave blocks per CU
 #endif
@@ -205,6 +211,47 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
     const float2 *Xr = yring + ((size_t)slot_r * n_streams + s) * PN_SPEC_BINS;   // X(t)  = Y(t-5)
     const float Ex = l < PN_NB ? eyring[((size_t)slot_r * n_streams + s) * 36 + l] : 0.f;   // Ex(t) = Ey(t-5)
     const float Ey = l < PN_NB ? eyring[((size_t)slot_w * n_streams + s) * 36 + l] : 0.f;   // Ey of this frame
+#if PN_FS_COMB_TAP_MAJOR
+    // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240q .. +3, q = 0..3; one unaligned dwordx4
+    // load per tap and quarter (the ring carries an 8-sample mirror).
+    // TAP-MAJOR order: tap k reads the 960 contiguous samples [2400 - T k, +960) as four back-to-back loads, and tap
+    // k + 1 reads the same window shifted down by T — the 960 - T samples two consecutive taps share (T <= 768: every
+    // frame) are requested again four loads later, while their lines are still in the cache hierarchy next to this CU,
+    // instead of microseconds later from another half of the kernel as in the quarter-major order of rounds 3-4
+    // (FETCH_SIZE 30.2 KB per stream against 21 KB of union window + spectra: the overlaps were re-fetched through the
+    // fabric).  The sums are the reference's: per output sample the seven products are added in tap order k = -3 .. 3
+    // onto 0 (denoise.cpp:419-421); only the order in which INDEPENDENT outputs advance changes.  Three register sets:
+    // the loads of tap k + 2 are issued before the multiply-adds of tap k.
+    float4 x[4];
+    {
+      fe_f4u cs[PN_FS_COMB_SETS][4];
+      float pa[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) pa[q][c] = 0;
+#define FS_COMB_LOAD(set, kk) do {                                                                    \
+        const int tap0_ = 2400 - pitch_index * ((kk) - PN_COMB_M) + 4 * lc;                           \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                 \
+          cs[set][q] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(tap0_ + 240 * q, base_slot));     \
+      } while (0)
+#pragma unroll
+      for (int k0 = 0; k0 < PN_FS_COMB_SETS - 1; k0++) FS_COMB_LOAD(k0, k0);
+#pragma unroll
+      for (int kk = 0; kk < 7; kk++) {
+        if (kk + PN_FS_COMB_SETS - 1 < 7) FS_COMB_LOAD((kk + PN_FS_COMB_SETS - 1) % PN_FS_COMB_SETS, kk + PN_FS_COMB_SETS - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) pa[q][c] += cs[kk % PN_FS_COMB_SETS][q][c] * cw[kk];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef FS_COMB_LOAD
+#pragma unroll
+      for (int q = 0; q < 4; q++) x[q] = make_float4(pa[q][0], pa[q][1], pa[q][2], pa[q][3]);
+    }
+#else    // the quarter-major order of rounds 3-4 (kept for A/B measurements)
     // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240k .. +3, k = 0..3; one unaligned dwordx4
     // load per tap (the ring carries an 8-sample mirror).  Two k at a time: 14 loads in flight.
     float4 x[4];
@@ -233,6 +280,7 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
         x[k0 + q] = make_float4(p[0], p[1], p[2], p[3]);
       }
     }
+#endif
     fs_fft_p1(F, SH.win, Z, x, l);
     float2 w[3][5];
     fs_fft_p23<false>(F, T, l, w);

@@ -37,6 +37,18 @@ void pn_launch_zero_rows(hipStream_t st, void *base, int row_floats, long long r
                          const int *d_ids, int n);
 void pn_launch_zero_shadow_rows(hipStream_t st, void *S, int width, int np, int n_slots, long long slot_stride_halfs,
                                 const int *d_ids, int n);
+// per-call active set (pn_active.hip): the rows ids[0..n) are the streams a call does NOT advance
+struct PnActiveArgs {
+  const int *ids;                                    // inactive stream ids (device)
+  float *synth; int *last_period; float *last_gain;  // in-place state
+  void *out; int out_row_words; float *d_gr;         // the caller's output rows (480 int16 = 240 words, or 480 floats); d_gr may be NULL
+  float *save_synth; uint32_t *save_out; float *save_gr; int *save_period; float *save_gain;   // save area, row i = ids[i]
+  float *hist; float2 *yring; float *eyring, *c1ring, *c2ring, *gru[4], *rb;
+  uint4 *c1ringH, *c2ringH, *gruH[4], *rbH; int np;  // operand shadows (np = 0: none)
+  long long B, Bp, t, tn;                            // t / tn: the counters of the tick the fix-up follows
+};
+void pn_launch_inactive_save(hipStream_t st, const PnActiveArgs &a, int n);
+void pn_launch_inactive_fixup(hipStream_t st, const PnActiveArgs &a, int n);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,
                        const float *ey_look_noisy, const float *aux_clean, const float *aux_noisy,
@@ -53,9 +65,9 @@ int pn_dense_nt(int N);
 size_t pn_packed_halfs_x3(int k_alloc, int ncols, int ct_round, int np /* planes: 2 = hi+lo (split precision), 1 = fp16 operands */);
 int pn_pack_weights_x3(const float *W, int K, int k_alloc, int ncols, int ct_round, int np, void *Wp);   // -1: weight outside fp16 range
 int pn_dense_x3_nt(int N);
-void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+int pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
                         const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg /* row groups of 32 per wave: 1 | 2 */, int np);
-void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
+int pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
                       int n_rows, int rg, int np);
 int pn_x3_rg_for(int n_rows);
@@ -65,15 +77,18 @@ void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, voi
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);
-void pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
+int pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
                          const float *tansig, float *out, int ldo, int n_rows);
+// The network launchers return 0, or -1 (pn_set_error) WITHOUT launching when they refuse a geometry: the caller fails
+// the frame (launch_rnn -> pn_process_*), it must never report a frame whose layer outputs are stale.
+// pn_check_dense_geometry / pn_check_gru_geometry (pn_launch_check.h) are the HIP-free predicates behind the refusals.
 // small: 1 = the small-batch kernel family (pn_nn_small.hip), 0 = the batch-GEMM kernels; ignored when strict.
 // pn_small_rows(): the batch size up to which a context picks the small family (PERCEPNET_SMALL_ROWS, default 4096).
 int pn_small_rows();
 int pn_small_gru_rows();
-void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
+int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small);
-void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
+int pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
                    float *h_new, int n_rows, int small);
 

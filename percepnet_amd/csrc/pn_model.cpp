@@ -72,6 +72,10 @@ pn_model *pn_model_from_sources(const PnLayerSrc *src) {
   if (total & 1) { uint32_t v; memcpy(&v, m->storage + total - 1, 4); mix(v); }
   for (int li = 0; li < PN_NLAYERS; li++) mix(((uint64_t)(uint32_t)m->L[li].act << 32) | (uint32_t)m->L[li].reset_after);
   m->content_hash = h;
+  uint64_t f = 0xcbf29ce484222325ull;                  // FNV-1a, byte-wise: shares no structure with the word-wise mix above
+  const unsigned char *bytes = (const unsigned char *)m->storage;
+  for (size_t i = 0; i < total * 4; i++) { f ^= bytes[i]; f *= 0x100000001b3ull; }
+  m->content_hash2 = f;
   return m;
 }
 

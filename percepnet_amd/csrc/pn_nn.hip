@@ -555,20 +555,19 @@ int pn_small_gru_rows() {
   const int d = pn_small_rows();
   return d < 1536 ? d : 1536;
 }
-void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
-                           const float *tansig, float *out, int ldo, int n_rows, int ct_padded);
-void pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
-                         const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
-void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
+int pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
+                          const float *tansig, float *out, int ldo, int n_rows, int ct_padded);
+int pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
+                        const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
+int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
                      int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small) {
   if (strict) {
     const int nbx = (N + 63) / 64;
     hipLaunchKernelGGL(pn_dense_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo, nbx);
-    return;
+    return 0;
   }
   if (small) {
-    pn_launch_dense_small(st, A, Wp, bias, N, act, tansig, out, ldo, n_rows, pn_ct_padded(N, pn_dense_nt(N)));
-    return;
+    return pn_launch_dense_small(st, A, Wp, bias, N, act, tansig, out, ldo, n_rows, pn_ct_padded(N, pn_dense_nt(N)));
   }
   const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
   const int NT = pn_dense_nt(N);
@@ -577,30 +576,31 @@ void pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
   // the half-tile pipeline consumes K-tiles in pairs: every layer of the PercepNet topology (the only geometry a
   // context accepts, pn_context.cpp:check_geometry) has an even number of them (4, 20, 48, 80, 4)
-  if (KT < 2 || (KT & 1)) { pn_set_error("pn_launch_dense: %d K-tiles (must be even)", KT); return; }
+  if (pn_check_dense_geometry("pn_launch_dense", A.n, A.width, 0)) return -1;
   if (NT == 4)
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   else
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
+  return 0;
 }
 
-void pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
+int pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
                    float *h_new, int n_rows, int small) {
   if (strict) {
     const int nbx = (N + 63) / 64;
     hipLaunchKernelGGL(pn_gru_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, X, h_old, W, U, b, N, act, tansig, h_new, nbx);
-    return;
+    return 0;
   }
   if (small) {
-    pn_launch_gru_small(st, X, h_old, Wp, Up, b, N, act, tansig, h_new, n_rows);
-    return;
+    return pn_launch_gru_small(st, X, h_old, Wp, Up, b, N, act, tansig, h_new, n_rows);
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
   hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows, n_mtiles);
+  return 0;
 }

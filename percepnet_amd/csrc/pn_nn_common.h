@@ -1,5 +1,6 @@
 // Shared device helpers of the network kernels (pn_nn.hip: fp32 MFMA + STRICT, pn_nn_small.hip, pn_nn_x3.hip: fp16 matrix cores).
 #pragma once
+#include "pn_launch_check.h"
 #include "pn_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));

@@ -290,31 +290,36 @@ __global__ __launch_bounds__(64, 1) void pn_dense_n16_kernel(        // (64, 1):
   }
 }
 
-void pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
-                         const float *tansig, float *out, int ldo, int n_rows) {
+int pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
+                        const float *tansig, float *out, int ldo, int n_rows) {
+  if (pn_check_n16_geometry("pn_launch_dense_n16", A.n, A.width, N16_DEPTH)) return -1;
   const int gps = A.width[0] / 16, KG = gps * A.n;      // equal-width panels, widths multiples of 16 (128, 512)
   const int n_mt = (n_rows + 15) / 16, n_ct = (N + 15) / 16;
-  if (KG % N16_DEPTH) { pn_set_error("pn_launch_dense_n16: %d k-groups (must be a multiple of %d)", KG, N16_DEPTH); return; }
   int lg = 0;
   while ((1 << lg) < gps) lg++;
-  if ((1 << lg) != gps) { pn_set_error("pn_launch_dense_n16: panel width %d is not a power of two", A.width[0]); return; }
   hipLaunchKernelGGL(pn_dense_n16_kernel, dim3(n_mt * n_ct), dim3(64), 0, st, A, Wq, bias, N, KG, lg, act, tansig, out, ldo,
                      n_rows, n_ct);
+  return 0;
 }
 
 // ---- launchers (called from pn_launch_dense / pn_launch_gru when the batch is small) -------------------------------
-void pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
-                           const float *tansig, float *out, int ldo, int n_rows, int ct_padded) {
+int pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
+                          const float *tansig, float *out, int ldo, int n_rows, int ct_padded) {
+  if (pn_check_dense_geometry("pn_launch_dense_small", A.n, A.width, 0)) return -1;   // K-tiles alternate between two register sets
   const int tps = (A.width[0] + 31) / 32, KT = tps * A.n;   // equal-width panels
   const int n_mt = (n_rows + SBM - 1) / SBM, ct_total = (N + 31) / 32, n_cblocks = (ct_total + 3) / 4;
   (void)ct_padded;
   hipLaunchKernelGGL(pn_dense_small_kernel, dim3(n_mt * n_cblocks), dim3(256), 0, st, A, Wp, bias, N, KT, tps, act, tansig,
                      out, ldo, n_rows, n_cblocks, ct_total);
+  return 0;
 }
-void pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
-                         const float *b, int N, int act, const float *tansig, float *h_new, int n_rows) {
+int pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
+                        const float *b, int N, int act, const float *tansig, float *h_new, int n_rows) {
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;
+  for (int j = 1; j < X.n; j++) if (X.width[j] != X.width[0]) { pn_set_error("pn_launch_gru_small: unequal panel widths"); return -1; }
+  if ((N & 31) || ((KTx + N / 32) & 1)) { pn_set_error("pn_launch_gru_small: %d input + %d recurrent K-tiles (the sum must be even, N whole tiles)", KTx, N / 32); return -1; }
   const int n_mt = (n_rows + SBM - 1) / SBM;
   hipLaunchKernelGGL(pn_gru_small_kernel, dim3(n_mt * (N / 32)), dim3(192), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                      tansig, h_new, n_rows);
+  return 0;
 }

@@ -869,14 +869,13 @@ int pn_x3_rg_for(int n_rows) {
 
 // A: panels carry the uint4* shadows of equally wide buffers (width = logical columns, a multiple of 32);
 // out (fp32, optional) / outS (shadow of a buffer nts_out column tiles wide, optional)
-void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
+int pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const float *bias, int N, int act,
                         const float *tansig, float *out, int ldo, void *outS, int nts_out, int n_rows, int rg, int np) {
   if (rg == 3) rg = 2;                 // the paired-phase form exists for the GRUs only
   const int tps = A.width[0] / 32, KT = tps * A.n;
   // the K loop consumes k-tiles in pairs and clamps its prefetch to the last tile: an odd count would accumulate that
   // tile twice; panels must be whole 32-column tiles of equal width (every layer of the fixed topology is: 20 / 48 / 80)
-  for (int j = 0; j < A.n; j++) if (A.width[j] != A.width[0]) { pn_set_error("pn_launch_dense_x3: unequal panel widths"); return; }
-  if ((A.width[0] & 31) || KT < 2 || (KT & 1)) { pn_set_error("pn_launch_dense_x3: %d k-tiles of panel width %d (need whole tiles, an even count)", KT, A.width[0]); return; }
+  if (pn_check_dense_geometry("pn_launch_dense_x3", A.n, A.width, 1)) return -1;
   const int NT = pn_dense_x3_nt(N);
   const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg);
   const int n_cblocks = x3_ct_padded(N, NT) / NT;
@@ -889,6 +888,7 @@ void pn_launch_dense_x3(hipStream_t st, const PnSegs &A, const void *Wp, const f
   if (NT == 4) XD_LAUNCH(4); else XD_LAUNCH(2);
 #undef XD_LAUNCH
 #undef XD_LAUNCH2
+  return 0;
 }
 
 // compute units of the current device (the paired-phase kernel runs one persistent block per CU)
@@ -904,16 +904,12 @@ static int x3_cu_count() {
   return cus[dev];
 }
 
-void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
+int pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const void *Wp,
                       const void *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
                       int n_rows, int rg, int np) {
   const int tps = X.width[0] / 32, KTx = tps * X.n;
   const int NTn = N / 32;
-  for (int j = 0; j < X.n; j++) if (X.width[j] != X.width[0]) { pn_set_error("pn_launch_gru_x3: unequal panel widths"); return; }
-  if ((X.width[0] & 31) || (N & 31) || (KTx & 1) || (NTn & 1)) {   // k-tiles are consumed in pairs (x: 16 / 32, h: 16 / 4)
-    pn_set_error("pn_launch_gru_x3: %d input and %d recurrent k-tiles (need whole tiles, even counts)", KTx, NTn); return; }
-  // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it
-  // is written for the tanh candidate and needs more K tiles than epilogue steps, otherwise the 64-rows-per-wave kernel
+  if (pn_check_gru_geometry("pn_launch_gru_x3", X.n, X.width, N)) return -1;   // k-tiles are consumed in pairs (x: 16 / 32, h: 16 / 4)
   // rg 3: paired-phase kernel (one 8-wave block per CU, K loop of one wave group beside the epilogue of the other); it
   // is written for the tanh candidate and instantiated for the two GRU geometries of the network (512 -> 512 and
   // 1024 -> 128); anything else runs on the 64-rows-per-wave kernel
@@ -926,7 +922,7 @@ void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const
     if (NTn == 16) { if (np == 2) XP_LAUNCH(2, 16, 16); else XP_LAUNCH(1, 16, 16); }
     else { if (np == 2) XP_LAUNCH(2, 32, 4); else XP_LAUNCH(1, 32, 4); }
 #undef XP_LAUNCH
-    return;
+    return 0;
   }
   if (rg == 3) rg = 2;
   const int n_mtiles = (n_rows + 128 * rg - 1) / (128 * rg);
@@ -938,6 +934,7 @@ void pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const
   if (np == 2) { if (rg == 2) XG_LAUNCH(2, 2); else XG_LAUNCH(1, 2); }
   else { if (rg == 2) XG_LAUNCH(2, 1); else XG_LAUNCH(1, 1); }
 #undef XG_LAUNCH
+  return 0;
 }
 
 void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np) {

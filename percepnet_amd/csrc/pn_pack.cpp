@@ -47,3 +47,18 @@ void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq) {
           Wq[(((size_t)ct * KG + t) * 64 + lane) * 4 + e] = (k < K && c < ncols) ? W[(size_t)k * ncols + c] : 0.f;
         }
 }
+
+// ---- launch-geometry predicates without a GPU (include/percepnet_hip.h: pn_debug_check_launch) ----------------------------
+#include "pn_launch_check.h"
+// kind: 0 dense on the fp32 MFMA kernels (batch and small-batch), 1 dense on the shadow-operand kernels, 2 GRU on the
+// shadow-operand kernels (n_out neurons), 3 narrow dense on 16x16x4 tiles.  n_panels panels of `width` columns each.
+extern "C" PN_EXPORT int pn_debug_check_launch(int kind, int n_panels, int width, int n_out) {
+  int w[5] = {width, width, width, width, width};
+  switch (kind) {
+    case 0: return pn_check_dense_geometry("pn_launch_dense", n_panels, w, 0);
+    case 1: return pn_check_dense_geometry("pn_launch_dense_x3", n_panels, w, 1);
+    case 2: return pn_check_gru_geometry("pn_launch_gru_x3", n_panels, w, n_out);
+    case 3: return pn_check_n16_geometry("pn_launch_dense_n16", n_panels, w, 8);
+    default: pn_set_error("pn_debug_check_launch: unknown kind %d", kind); return -1;
+  }
+}

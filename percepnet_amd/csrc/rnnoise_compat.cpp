@@ -8,7 +8,9 @@
 //
 // One DenoiseState = a batch-of-one context.  That is correct but launch-bound (15 kernel
 // launches and two PCIe hops per 10 ms frame); throughput lives in the batched pn_* API.  N handles of one model share
-// one device copy of the weights (pn_context.cpp: SharedWeights) and, when they borrow the same RNNModel, one host copy.
+// ONE DEVICE copy of the weights (pn_context.cpp: SharedWeights, found by content); each handle still owns its host-side
+// pn_model (a 32 MB copy of the arrays it was given, hashed once): the RNNModel a caller passes is borrowed memory that
+// may be changed or freed between two rnnoise_init calls, so nothing host-side is keyed on its address here.
 #include "pn_common.h"
 #include "../../include/percepnet_hip.h"
 // the reference's own (C++-mangled) entry points: exported like the C-ABI (the library is built with -fvisibility=hidden)

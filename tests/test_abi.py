@@ -98,3 +98,25 @@ def test_relinked_reference_cli_is_never_silently_inert(lib, blob, tmp_path):
                            env=dict(env, PERCEPNET_MODEL=str(tmp_path / "m.pnw")))
         assert r.returncode == 0 and "INERT" in r.stderr and "no CPU fallback" in r.stderr
         assert not np.fromfile(tmp_path / "o.pcm", np.int16).any()
+
+
+def test_launch_geometry_refusals_without_gpu(lib):
+    """Round-4 verdict item 8, CPU side: the network launchers' geometry predicates (csrc/pn_launch_check.h, reached
+    through pn_debug_check_launch) accept every layer of the PercepNet topology and refuse, with pn_last_error() set, what
+    their software pipelines cannot run — the GPU test (test_a_refused_launch_fails_the_frame) shows that a refusal
+    fails pn_process_*."""
+    import ctypes
+    lib.pn_debug_check_launch.argtypes = [ctypes.c_int] * 4
+    lib.pn_last_error.restype = ctypes.c_char_p
+    # (kind, panels, width, n_out) of the layers as pn_context.cpp launches them
+    topology = [(0, 1, 128, 128), (0, 5, 128, 512), (0, 3, 512, 512), (0, 5, 512, 34), (0, 1, 128, 34),
+                (1, 5, 128, 512), (1, 3, 512, 512), (1, 5, 512, 34), (2, 1, 512, 512), (2, 2, 512, 128),
+                (3, 5, 512, 34), (3, 1, 128, 34)]
+    for g in topology:
+        assert lib.pn_debug_check_launch(*g) == 0, (g, lib.pn_last_error())
+    refused = [((0, 3, 32, 34), b"even"), ((0, 1, 32, 34), b"even"), ((0, 6, 128, 34), b"panels"), ((1, 3, 500, 34), b"whole"),
+               ((2, 1, 512, 96), b"neurons"), ((2, 1, 32, 512), b"even"), ((3, 1, 48, 34), b"power-of-two"), ((3, 3, 16, 34), b"multiple"),
+               ((9, 1, 128, 34), b"unknown kind")]
+    for g, word in refused:
+        assert lib.pn_debug_check_launch(*g) == -1, g
+        assert word in lib.pn_last_error(), (g, lib.pn_last_error())
