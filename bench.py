@@ -236,9 +236,19 @@ def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
         r["peak_note"] = ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (three fp16 MFMA products per fp32 product); executed MFMA rate = "
                           f"{round(3 * ach, 1)} TFLOP/s; the fp32 MFMA peak this replaces is {PEAK_FP32_MFMA_TFLOPS} TFLOP/s")
     if fps is not None:
+        # report BOTH bounds of the whole pipeline and say which one binds
+        hbm_bytes = 62608 + 31850256 / B
         r["whole_pipeline_tflops"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12, 2)
         r["whole_pipeline_frac_of_mfma_peak"] = round(fps / n_gpus * FLOP_PER_STREAM_FRAME / 1e12 / peak, 4)
-        r["algorithmic_hbm_gbs"] = round(fps / n_gpus * (62608 + 31850256 / B) / 1e9, 1)
+        r["algorithmic_hbm_gbs"] = round(fps / n_gpus * hbm_bytes / 1e9, 1)
+        r["whole_pipeline_frac_of_hbm_peak"] = round(fps / n_gpus * hbm_bytes / 1e12 / PEAK_HBM_TBS, 4)
+        intensity = FLOP_PER_STREAM_FRAME / hbm_bytes
+        ridge = peak * 1e12 / (PEAK_HBM_TBS * 1e12)
+        r["both_bounds"] = {"mfma": {"peak_tflops": peak, "frac_dominant_kernel": r["frac"], "frac_whole_pipeline": r["whole_pipeline_frac_of_mfma_peak"]},
+                            "hbm": {"peak_gbs": PEAK_HBM_TBS * 1e3, "frac_whole_pipeline": r["whole_pipeline_frac_of_hbm_peak"]},
+                            "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                            "binding": "hbm" if intensity < ridge else "mfma",
+                            "note": "at these operand rates the whole pipeline sits " + ("BELOW the ridge: HBM binds" if intensity < ridge else "above the ridge: the matrix pipe binds")}
     return r
 
 
@@ -275,13 +285,20 @@ def pmc_kernel_counters(kernel_prefix, tag=""):
     return {r["counter"]: float(r["avg"]) for r in recs if r["kernel"].endswith(f"grid={g}")}, os.path.basename(fresh[-1])
 
 
-def dsp_roofline(kt, B, tag=""):
+SPEC_OUT_FIXED = 3200 + 288 + 3200 + 512 + 4          # X + two band-energy rows read | comb-filtered spectrum + feature row + silence flag written
+
+
+def dsp_roofline(kt, B, tag="", periods=None):
     """HBM roofline of the DSP kernels, ONE OBJECT PER KERNEL: `achieved` = algorithmic bytes of that kernel / its HIP-event
     time; `traffic` = HBM-side bytes per launch from the rocprofv3 counters of the same kernels (FETCH_SIZE x 2 — the gfx950
-    counter tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 B, MI355X_MICROARCH.md; these kernels
-    read their history, spectra and PCM rows with dwordx4 / dwordx2 loads, for which the correction was calibrated; the scalar
-    4-byte loads of fe_pitch's window are the uncalibrated remainder — + WRITE_SIZE as is), `traffic_gbs` the same over the
-    event time, `traffic_over_algorithmic` what the phase split and re-reads cost.  `frontend` / `dsp_total` lump them."""
+    counter tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 B, MI355X_MICROARCH.md; calibrated for this
+    kernel family's own access patterns, the comb filter's UNALIGNED dwordx4 windows included, by
+    tools/probes/fetch_unaligned_probe.hip: profiles/r05_fetch_size_calibration.log — + WRITE_SIZE as is), `traffic_gbs` the same
+    over the event time, `traffic_over_algorithmic` what the phase split and re-reads cost.
+    periods (int array, one per stream): the pitch periods the run's own last frame filtered at (pn_ctx_debug_copy 13).  The comb
+    filter of a stream reads the window [2400 - 3T, 3360 + 3T) = 960 + 6T samples (reference denoise.cpp:416-422), so
+    fe_spec_out's algorithmic bytes are sum_s (960 + 6 T_s) * 4 + the fixed rows — they FOLLOW FROM THE RUN; the figure for the
+    longest period (T = 768) is kept as `algorithmic_bytes_worst_case`.  `frontend` / `dsp_total` lump the kernels."""
     out, tot_ms, tot_alg, tot_tr = {}, 0.0, 0, 0
     for fam, (kname, per_stream) in DSP_KERNELS.items():
         ms, n = kt.get(fam, (0.0, 0))
@@ -289,9 +306,22 @@ def dsp_roofline(kt, B, tag=""):
             continue
         ms /= n
         alg = B * per_stream
+        extra = {}
+        if fam == "fe_spec_out":
+            extra["algorithmic_bytes_worst_case"] = alg
+            if periods is not None and len(periods) == B:
+                import numpy as np
+                T = np.asarray(periods, dtype=np.int64)
+                alg = int(((960 + 6 * T) * 4).sum()) + B * SPEC_OUT_FIXED
+                extra["pitch_period_mean"] = round(float(T.mean()), 1)
+                extra["comb_window_bytes_mean"] = round(float(((960 + 6 * T) * 4).mean()), 1)
+                extra["algorithmic_bytes_source"] = "sum over this run's streams of (960 + 6 T) * 4 (T = the period the last frame filtered at) + fixed rows"
+            else:
+                extra["algorithmic_bytes_source"] = "worst case (T = 768): the run's periods were not read"
         o = {"kernel": kname, "bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": alg,
              "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
              "frac": round(alg / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
+        o.update(extra)
         ctr, src = pmc_kernel_counters(kname, tag)
         if ctr and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
             tr = ctr["FETCH_SIZE"] * 1024 * 2 + ctr["WRITE_SIZE"] * 1024
@@ -310,8 +340,8 @@ def dsp_roofline(kt, B, tag=""):
                             "traffic": tot_tr or None, "traffic_over_algorithmic": round(tot_tr / tot_alg, 3) if tot_tr else None,
                             "whole_pipeline_minimum_bytes": B * (62608 - 29696),
                             "traffic_over_whole_pipeline_minimum": round(tot_tr / (B * (62608 - 29696)), 3) if tot_tr else None,
-                            "note": "per-kernel algorithmic bytes count the history window once per kernel that needs it; "
-                                    "whole_pipeline_minimum_bytes is SURVEY 8(d)'s 62 608 - 29 696 B per stream-frame"}
+                            "note": "per-kernel algorithmic bytes count the history window once per kernel that needs it (fe_spec_out: the "
+                                    "window of each stream's own period); whole_pipeline_minimum_bytes is SURVEY 8(d)'s 62 608 - 29 696 B per stream-frame"}
     # the single-launch front ends (PERCEPNET_FE=mono|g2) have no per-phase kernels
     fe = kt.get("frontend", (0.0, 0))
     if fe[1]:
@@ -319,6 +349,15 @@ def dsp_roofline(kt, B, tag=""):
         out["frontend"] = {"bound": "hbm", "ms": round(ms, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3,
                            "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4), "algorithmic_bytes": by}
     return out
+
+
+def read_periods(ctx, B):
+    """The pitch period every stream's comb filter used in the context's last frame (int32 per stream)."""
+    import numpy as np
+    try:
+        return np.frombuffer(ctx.debug_copy(13, B).tobytes(), dtype=np.int32).copy()
+    except Exception:                         # noqa: BLE001 — the roofline then falls back to the worst case and says so
+        return None
 
 
 def gpu_clock_mhz():
@@ -366,28 +405,40 @@ def percentiles(ms):
             "mean": round(float(a.mean()), 4), "frames": int(a.size)}
 
 
-def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0):
+DELIVERY_DEADLINE_MS = 20.0          # two frame periods = the depth of the pipelined host path (two frames in flight)
+
+
+def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=None):
     """The real-time contract itself (reference main.cpp:30-39: one 480-sample frame per stream every 10 ms), not an
     extrapolation from a mean: a frame of B streams arrives on the HOST every 10.000 ms for `seconds` and goes through the
     pipelined host entry points (pn_submit_host_i16: pinned buffers, copy-in / compute / copy-out on three streams, two
     frames in flight).  Frame t is submitted at its arrival time a_t = t0 + 10 ms x t (or as soon as the previous call
-    returns, if that is later); the call returns when frame t - 2 has been delivered.  A frame MISSES its deadline when the
-    system has fallen behind its input: the submit call for frame t returns after frame t + 1 has already arrived."""
+    returns, if that is later).  Two things are measured per frame:
+      * back-pressure: the submit call for frame t returns after frame t + 1 has already arrived (`deadline_misses`);
+      * ARRIVAL-TO-DELIVERY latency: between arrivals the loop polls pn_host_frames_delivered (event queries) and stamps
+        every frame whose output copy has landed (resolution ~0.2 ms): `delivery_latency_ms` p50 / p99 / max.
+    `met_contract`: no back-pressure miss, delivery p99 within DELIVERY_DEADLINE_MS (the pipeline is two frames deep: a
+    frame must be out before the frame after next arrives), and the run did not end behind its clock.
+    ctx: reuse an open context of B streams (reset first); otherwise one is created and closed here."""
     import ctypes
     import numpy as np
-    ctx = api.Context(model, B, device=dev_index, nn_mode=nn_mode)
+    own = ctx is None
+    if own:
+        ctx = api.Context(model, B, device=dev_index, nn_mode=nn_mode)
+    else:
+        ctx.host_wait(); ctx.reset()
     L = ctx.L
     n = B * FRAME
+    bufs = []
     try:
         src = synth.synth_batch(min(B, 64), 3, base_seed=synth.BASE_SEED + 31337)
-        bufs = []
         for k in range(3):
             hin, hout = L.pn_host_alloc(n * 2), L.pn_host_alloc(n * 2)
             if not hin or not hout:
                 raise RuntimeError("pinned allocation failed")
+            bufs.append((hin, hout))
             fr = np.ascontiguousarray(src[np.arange(B) % src.shape[0], k * FRAME:(k + 1) * FRAME])
             ctypes.memmove(hin, fr.ctypes.data, n * 2)
-            bufs.append((hin, hout))
         for k in range(6):                                   # warm the pipeline (streams, staging buffers, clocks)
             ctx.submit_host_i16(*bufs[k % 3])
         ctx.host_wait()
@@ -397,36 +448,173 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0):
             if L.pn_process_host_i16(ctx.h, bufs[k][0], bufs[k][1], None):
                 raise RuntimeError("pn_process_host_i16 failed")
             ser.append(time.perf_counter() - t_s)
+        base = L.pn_host_frames_delivered(ctx.h)             # frames delivered before the paced loop starts
+        if base < 0:
+            raise RuntimeError("pn_host_frames_delivered failed")
         N = int(seconds * 100)
         period = 0.010
-        arrive = np.empty(N); ret = np.empty(N); start = np.empty(N)
+        arrive = np.empty(N); ret = np.empty(N); start = np.empty(N); deliv = np.full(N, np.nan)
+        nd = 0
+
+        def poll(now):
+            nonlocal nd
+            d = L.pn_host_frames_delivered(ctx.h) - base
+            while nd < min(d, N):
+                deliv[nd] = now; nd += 1
+
         with ClockSampler() as clk:
             t0 = time.perf_counter() + 0.002
             for t in range(N):
                 a_t = t0 + period * t
-                while True:                                  # sleep most of the wait, spin the last 300 us
+                while True:                                  # poll deliveries while waiting for the arrival; sleep in 0.2 ms steps
                     now = time.perf_counter()
+                    poll(now)
                     if now >= a_t:
                         break
-                    if a_t - now > 0.0005:
-                        time.sleep(a_t - now - 0.0003)
+                    if a_t - now > 0.0004:
+                        time.sleep(0.0002)
                 arrive[t] = a_t; start[t] = now
                 ctx.submit_host_i16(*bufs[t % 3])
                 ret[t] = time.perf_counter()
+                poll(ret[t])
+            while nd < N and time.perf_counter() < t0 + period * N + 1.0:     # the last two frames
+                poll(time.perf_counter()); time.sleep(0.0002)
             ctx.host_wait()
             t_end = time.perf_counter()
+            poll(t_end)
         late = ret[:-1] - arrive[1:]                          # > 0: the call for frame t came back after frame t + 1 had arrived
         backlog = start - arrive                              # how far behind its arrival a frame was submitted
+        lat = (deliv - arrive) * 1e3
+        lat = lat[~np.isnan(lat)]
         out = {"streams": B, "seconds": round(t_end - t0, 3), "frames": N, "period_ms": 10.0,
                "deadline_misses": int((late > 0).sum()), "max_lateness_ms": round(float(max(late.max(), 0.0)) * 1e3, 4),
+               "delivery_latency_ms": percentiles(lat) if lat.size else None, "delivery_deadline_ms": DELIVERY_DEADLINE_MS,
+               "frames_delivered_late": int((lat > DELIVERY_DEADLINE_MS).sum()),
                "submit_call_ms": percentiles((ret - start) * 1e3), "submit_backlog_ms_max": round(float(backlog.max()) * 1e3, 4),
                "finished_behind_schedule_ms": round((t_end - (t0 + period * N)) * 1e3, 4),
                "serial_host_call_ms": round(1e3 * min(ser), 3),
-               "path": "pn_submit_host_i16 (pinned host buffers, PCIe both ways inside the loop)"}
+               "path": "pn_submit_host_i16 (pinned host buffers, PCIe both ways inside the loop); delivery stamped by polling "
+                       "pn_host_frames_delivered between arrivals (~0.2 ms resolution)"}
+        out["met_contract"] = bool(out["deadline_misses"] == 0 and lat.size == N and out["delivery_latency_ms"]["p99"] <= DELIVERY_DEADLINE_MS
+                                   and out["finished_behind_schedule_ms"] < 10.0)
         out.update(clk.summary())
         return out
     finally:
-        ctx.close()
+        try:
+            ctx.host_wait()
+        except Exception:                     # noqa: BLE001
+            pass
+        for hin, hout in bufs:
+            L.pn_host_free(hin); L.pn_host_free(hout)
+        if own:
+            ctx.close()
+
+
+def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log):
+    """Deadline-PROVEN capacity (round-4 verdict item 4): the largest batch in 65 536 .. 69 632 (512-stream grid) that meets
+    the paced contract in EVERY one of `runs` runs, found by bisection (a larger batch is never easier), plus the pass rate
+    of the next size up.  Falls back to smaller batches when 65 536 itself fails."""
+    grid = [65536 + 512 * k for k in range(9)]
+    tried = {}
+
+    def probe(b):
+        res = []
+        try:
+            ctx = api.Context(model, b, device=dev_index, nn_mode=nn_mode)
+        except Exception as e:                # noqa: BLE001
+            tried[b] = [{"streams": b, "error": f"{type(e).__name__}: {e}"}]
+            return False
+        try:
+            for _ in range(runs):
+                try:
+                    res.append(paced_realtime(api, synth, model, dev_index, b, nn_mode, seconds, ctx=ctx))
+                except Exception as e:        # noqa: BLE001
+                    res.append({"streams": b, "error": f"{type(e).__name__}: {e}"})
+        finally:
+            ctx.close()
+        tried[b] = res
+        ok = all(r.get("met_contract") for r in res)
+        log(f"[bench] paced real-time {b} streams: {sum(bool(r.get('met_contract')) for r in res)}/{len(res)} runs met the contract")
+        return ok
+
+    best = None
+    if probe(grid[0]):
+        lo, hi = 0, len(grid)                 # grid[lo] passes; grid[hi] (if any) fails
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if probe(grid[mid]):
+                lo = mid
+            else:
+                hi = mid
+        best = grid[lo]
+        nxt = grid[hi] if hi < len(grid) else None
+    else:
+        nxt = grid[0]
+        for b in (61440, 57344, 53248, 49152):
+            if probe(b):
+                best = b
+                break
+    summary = {b: {"runs": len(r), "passed": sum(bool(x.get("met_contract")) for x in r),
+                   "deadline_misses": [x.get("deadline_misses") for x in r],
+                   "delivery_latency_ms_p99": [(x.get("delivery_latency_ms") or {}).get("p99") for x in r]} for b, r in sorted(tried.items())}
+    return {"realtime_streams_p99": best,
+            "next_size": None if nxt is None else {"streams": nxt, "runs": summary[nxt]["runs"], "passed": summary[nxt]["passed"]},
+            "sizes": {str(b): v for b, v in summary.items()},
+            "paced_runs": [r for b in sorted(tried) for r in tried[b]],
+            "runs_per_size": runs, "seconds_per_run": seconds, "grid": "65536 + 512 k, k = 0..8",
+            "contract": "one 480-sample frame per stream every 10 ms (reference src/main.cpp:30-39): frames arrive on the host on a 10.000 ms "
+                        f"clock, pipelined host path with PCIe in the loop; a run passes with zero back-pressure misses, delivery p99 <= "
+                        f"{DELIVERY_DEADLINE_MS} ms after arrival and no schedule slip; a size passes when ALL its runs pass"}
+
+
+def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026):
+    """65 536 DISTINCT streams (round-4 verdict item 4): the headline tiles 64 pool streams over the batch, so the
+    data-dependent paths of the pitch kernel see 64 behaviours.  Here every stream is synthesised on the device from its own
+    parameters — a harmonic tone with its own fundamental (60-500 Hz, gliding), harmonic count, level (5 % near full scale, so
+    the non-silent branch runs) and noise floor — and the same K steps are timed with per-kernel events."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    T = K + W
+    f0 = 60.0 + 440.0 * torch.rand(B, 1, device=dev, generator=g)
+    glide = 1.0 + 0.2 * (torch.rand(B, 1, device=dev, generator=g) - 0.5)
+    nh = torch.randint(1, 9, (B, 1), device=dev, generator=g).float()
+    loud = torch.rand(B, 1, device=dev, generator=g) < 0.05
+    amp = torch.where(loud, 20000.0 + 10000.0 * torch.rand(B, 1, device=dev, generator=g), 300.0 + 5000.0 * torch.rand(B, 1, device=dev, generator=g))
+    noise = 20.0 + 400.0 * torch.rand(B, 1, device=dev, generator=g)
+    ph0 = 6.2831853 * torch.rand(B, 1, device=dev, generator=g)
+    frames = []
+    for t in range(T):
+        nidx = (t * FRAME + torch.arange(FRAME, device=dev, dtype=torch.float32))[None, :]
+        f = f0 * (1.0 + (glide - 1.0) * nidx / (T * FRAME))
+        ph = ph0 + 6.2831853 * f * nidx / 48000.0
+        x = torch.zeros((B, FRAME), device=dev)
+        for h in range(1, 9):
+            x += torch.where(nh >= h, torch.sin(h * ph) / h, torch.zeros((), device=dev))
+        x = amp * x + noise * torch.randn((B, FRAME), device=dev, generator=g)
+        frames.append(x.clamp_(-32768, 32767).to(torch.int16).contiguous())
+    out = torch.empty((B, FRAME), dtype=torch.int16, device=dev)
+    distinct = int(torch.unique(torch.stack([f[:, :8].to(torch.int64) for f in frames[:2]], 1).reshape(B, -1), dim=0).shape[0])
+    torch.cuda.synchronize()
+    ctx.reset()
+    for t in range(W):
+        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
+    torch.cuda.synchronize()
+    ctx.reset_profile(); ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for t in range(W, T):
+        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    kt = ctx.kernel_times()
+    import numpy as np
+    per = np.frombuffer(ctx.debug_copy(13, B).tobytes(), dtype=np.int32)
+    return {"streams": B, "distinct_streams": distinct, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 4),
+            "value": round(B * K / dt / 100.0, 1), "unit": "streams",
+            "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if v[1]},
+            "pitch_period_of_last_frame": {"min": int(per.min()), "mean": round(float(per.mean()), 1), "max": int(per.max()),
+                                           "distinct_values": int(np.unique(per).size)},
+            "data": "per-stream harmonic tones synthesised on the device (own fundamental 60-500 Hz with glide, 1-8 harmonics, own level "
+                    "and noise floor, 5 % near full scale), no two streams alike"}
 
 
 def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, traffic_tag):
@@ -461,6 +649,7 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
         ctx.set_profiling(False)
         kt = ctx.kernel_times()
         desc = ctx.describe()
+        periods = read_periods(ctx, B)
     finally:
         ctx.close()
     # a SMALL batch is a latency figure: ms_per_step is the result, and a "streams" number would be an extrapolation of a
@@ -476,8 +665,8 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
             "kernel_families": desc,
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
             "dtype": DTYPE_OF_MODE[nn_mode],
-            "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, traffic_tag=traffic_tag),
-            "dsp_roofline": dsp_roofline(kt, B, traffic_tag),
+            "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, 1, B * K / dt, traffic_tag=traffic_tag),
+            "dsp_roofline": dsp_roofline(kt, B, traffic_tag, periods),
             "whole_pipeline_hbm": {"algorithmic_gbs": round(B * K / dt * (62608 + 31850256 / B) / 1e9, 1),
                                    "frac_of_peak": round(B * K / dt * (62608 + 31850256 / B) / 1e12 / PEAK_HBM_TBS, 4),
                                    "note": "SURVEY 8(d): bytes(B) = 62 608 + 31 850 256 / B per stream-frame at the measured rate"}}
@@ -520,6 +709,36 @@ def drop_in_single_stream(frames=1000):
             "wall_s": {str(k): round(v, 3) for k, v in times.items()}}
 
 
+def sustained_leg(ctx, frames, out, stream, torch, B, K, T, dt, seconds):
+    """The step loop without per-kernel events for >= `seconds`, ONE completion event per frame read after the loop."""
+    n_sus, ds, per = 0, 0.0, max(dt / K, 1e-6)
+    ev = []                                              # one event per frame, read after the loop: per-frame completion times
+    torch.cuda.synchronize()
+    with ClockSampler() as clk:
+        while ds < seconds:                              # chunks sized from the rate seen so far; one sync per chunk
+            n = max(K, int((seconds - ds) / per * 1.05) + 1)
+            t0 = time.perf_counter()
+            for i in range(n):
+                ctx.process_i16_dev(frames[(n_sus + i) % T].data_ptr(), out.data_ptr(), None)
+                e = torch.cuda.Event(enable_timing=True); e.record(stream); ev.append((len(ev) == 0 or i == 0, e))
+            torch.cuda.synchronize()
+            ds += time.perf_counter() - t0
+            n_sus += n
+            per = ds / n_sus
+    # interval between the completions of consecutive frames = the time the GPU took for that frame (the queue is
+    # never empty inside a chunk; the first frame of a chunk follows a host synchronise and is left out)
+    frame_ms = [ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev)) if not ev[i][0]]
+    pc = percentiles(frame_ms) if frame_ms else {}
+    r = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 4),
+         "value": round(B * n_sus / ds / 100.0, 1), "unit": "streams",
+         "frame_ms_p50": pc.get("p50"), "frame_ms_p99": pc.get("p99"), "frame_ms_max": pc.get("max"),
+         "frames_timed": pc.get("frames"), "sclk_mhz_at_end": gpu_clock_mhz(),
+         "note": "no per-kernel events in this loop (one completion event per frame); the K-step figure above is "
+                 "the contract's; frame_ms_* = intervals between consecutive frame completions on the GPU"}
+    r.update(clk.summary())
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launched world, else 1")
@@ -534,7 +753,10 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained-rate loop after the timed region")
     ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--no-realtime", action="store_true", help="skip the paced 10 ms-clock runs through the pipelined host path")
-    ap.add_argument("--realtime-seconds", type=float, default=10.0)
+    ap.add_argument("--realtime-seconds", type=float, default=6.0, help="length of one paced run")
+    ap.add_argument("--realtime-runs", type=int, default=3, help="paced runs per batch size (a size passes when all of them do)")
+    ap.add_argument("--no-distinct", action="store_true", help="skip the timed run on 65 536 streams that are all different")
+    ap.add_argument("--no-numa", action="store_true", help="do not bind the rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
     ap.add_argument("--fp16", action="store_true",
                     help="BASELINE configs[4]: fp16 GEMM operands, fp32 accumulate (tolerance re-stated: bound 6 LSB, 4 measured over 1024 x 1000)")
@@ -556,12 +778,15 @@ def main():
         if launched and world > 1:
             print(f"[bench] --gpus not given: adopting the launched world of {world} rank(s)", file=sys.stderr, flush=True)
     if not launched and (a.gpus > 1 or a.force_dist):
-        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
-        sys.exit(sharding.spawn_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU).  The CPU baseline is timed
+        # HERE, once, on the still idle host, and handed to rank 0 (sharding.cpu_baseline_handoff): an N-GPU line carries it too
+        sys.exit(sharding.spawn_with_cpu_baseline(a.gpus, os.path.abspath(__file__), sys.argv[1:], None if a.no_cpu_baseline else cpu_baseline))
 
     cpu = None
-    if rank == 0 and world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline()          # before HIP is initialised in this process (fork safety)
+    if not a.no_cpu_baseline:
+        # rank 0 only; before HIP is initialised in this process (fork safety) and — when the ranks were launched by
+        # torch.distributed.run directly — before it joins the process group: the other ranks are blocked in the rendezvous
+        cpu = sharding.cpu_baseline_handoff(cpu_baseline, world, rank)
 
     import numpy as np
     import torch
@@ -576,6 +801,11 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # NUMA placement BEFORE any pinned host buffer exists (first touch): this rank's CPUs = those of its GPU's NUMA node
+    props0 = torch.cuda.get_device_properties(local_rank)
+    bdf = "%04x:%02x:%02x.0" % (getattr(props0, "pci_domain_id", 0), getattr(props0, "pci_bus_id", 0), getattr(props0, "pci_device_id", 0))
+    numa = sharding.numa_bind_for_device(bdf, bind=not a.no_numa)
+    numa["rank"] = rank
     dist = sharding.init_ranks(a.backend, a.gpus, dev)       # refuses WORLD_SIZE != --gpus; joins a world of one too
     n_gpus = world
 
@@ -633,19 +863,52 @@ def main():
 
     kt = {} if a.no_profile else ctx.kernel_times()
     checksum = int(out.to(torch.int64).abs().sum().item())     # keeps the result live / sanity
+    periods = read_periods(ctx, B)                              # the periods this run's last frame filtered at (dsp_roofline)
     if os.environ.get("PN_BENCH_DUMP"):                         # debugging aid: last frame's PCM of this rank
         import numpy as _np
         _np.save(os.environ["PN_BENCH_DUMP"], out.cpu().numpy())
+    log = lambda m: print(m, file=sys.stderr, flush=True)       # noqa: E731
+    nn_mode = api.NN_STRICT if a.strict else (api.NN_MFMA_F16 if a.fp16 else (api.NN_MFMA_X3 if a.x3 else api.NN_MFMA))
+
+    parity = None
+    if rank == 0 and not a.no_parity and not a.strict:
+        parity = measure_parity(ctx, frames, pool_np, out, torch)
+
+    # ---- legs EVERY rank runs, side by side (one host feeding N GPUs), gathered like `ranks` -----------------------------
+    # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
+    # are 0.2 s, shorter than the time the chip needs to settle on its power-limited clock.
+    sustained = None
+    if not a.no_sustained and not a.strict:
+        sharding.barrier(dist)
+        sustained = sustained_leg(ctx, frames, out, stream, torch, B, K, T, dt, a.sustained_seconds)
+        sustained["rank"] = rank
+    # The real-time claim, measured: frames arriving every 10.000 ms on the host through the pipelined host path (each rank
+    # its own pinned buffers, allocated after its NUMA binding).  N = 1, headline workload: the deadline-proven capacity
+    # search; otherwise one paced run at this batch size on every rank at the same time.
+    realtime_rank, capacity = None, None
+    if not (a.strict or a.no_sustained or a.no_realtime):
+        sharding.barrier(dist)
+        if world == 1 and B == 65536 and nn_mode == api.NN_MFMA:
+            capacity = realtime_capacity(api, synth, model, local_rank, nn_mode, a.realtime_seconds, a.realtime_runs, log)
+            at_b = [r for r in capacity["paced_runs"] if r.get("streams") == B]
+            realtime_rank = at_b[0] if at_b else None
+        else:
+            try:
+                realtime_rank = paced_realtime(api, synth, model, local_rank, B, nn_mode, a.realtime_seconds)
+            except Exception as e:              # noqa: BLE001 — reported, not fatal
+                realtime_rank = {"streams": B, "error": f"{type(e).__name__}: {e}"}
+        if realtime_rank is not None:
+            realtime_rank = dict(realtime_rank, rank=rank)
+    fields = sharding.multi_rank_fields(dist, cpu, numa, sustained, realtime_rank)
 
     if rank == 0:
-        parity = None
-        if not a.no_parity and not a.strict:
-            parity = measure_parity(ctx, frames, pool_np, out, torch)
         desc = ctx.describe()
         res = {
             "metric": "real-time 48 kHz streams (10 ms frames), whole job",
             "value": round(fps / 100.0, 1),
             "unit": "streams",
+            "value_note": "`value` = stream-frames per second / 100 over the K timed steps (throughput expressed in 10 ms streams; it is "
+                          "not a batch that ran); the deadline-PROVEN capacity is `realtime_streams_p99` (paced 10 ms clock, PCIe in the loop)",
             "frames_per_s": round(fps, 1),
             "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 4),
@@ -679,55 +942,28 @@ def main():
             rl = gru_roofline(kt, B, a.fp16, desc, n_gpus, fps, traffic_tag=tag)
             if rl:
                 res["roofline"] = rl
-            res["dsp_roofline"] = dsp_roofline(kt, B, tag)
-        if cpu is not None:
-            res["cpu_baseline"] = cpu
-        # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
-        # are 0.2 s, shorter than the time the chip needs to settle on its power-limited clock.
-        if world == 1 and not a.no_sustained and not a.strict:
-            n_sus, ds, per = 0, 0.0, max(dt / K, 1e-6)
-            ev = []                                              # one event per frame, read after the loop: per-frame completion times
-            torch.cuda.synchronize()
-            with ClockSampler() as clk:
-                while ds < a.sustained_seconds:                  # chunks sized from the rate seen so far; one sync per chunk
-                    n = max(K, int((a.sustained_seconds - ds) / per * 1.05) + 1)
-                    t0 = time.perf_counter()
-                    for i in range(n):
-                        ctx.process_i16_dev(frames[(n_sus + i) % T].data_ptr(), out.data_ptr(), None)
-                        e = torch.cuda.Event(enable_timing=True); e.record(stream); ev.append((len(ev) == 0 or i == 0, e))
-                    torch.cuda.synchronize()
-                    ds += time.perf_counter() - t0
-                    n_sus += n
-                    per = ds / n_sus
-            # interval between the completions of consecutive frames = the time the GPU took for that frame (the queue is
-            # never empty inside a chunk; the first frame of a chunk follows a host synchronise and is left out)
-            frame_ms = [ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev)) if not ev[i][0]]
-            pc = percentiles(frame_ms) if frame_ms else {}
-            res["sustained"] = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 4),
-                                "value": round(B * n_sus / ds / 100.0, 1), "unit": "streams",
-                                "frame_ms_p50": pc.get("p50"), "frame_ms_p99": pc.get("p99"), "frame_ms_max": pc.get("max"),
-                                "frames_timed": pc.get("frames"), "sclk_mhz_at_end": gpu_clock_mhz(),
-                                "note": "no per-kernel events in this loop (one completion event per frame); the K-step figure above is "
-                                        "the contract's; frame_ms_* = intervals between consecutive frame completions on the GPU"}
-            res["sustained"].update(clk.summary())
-        # The real-time claim, measured: frames arriving every 10.000 ms on the host for >= 10 s through the pipelined host path,
-        # at this batch size and — while a run still misses deadlines — at smaller ones.  `realtime_streams_p99` = the
-        # largest batch tried that met every deadline with a 99th-percentile frame time under 10 ms.
-        if world == 1 and B == 65536 and not (a.strict or a.fp16 or a.x3 or a.no_sustained or a.no_realtime):
-            runs, ok = [], None
-            for b2 in (67584, 65536, 61440, 59392, 57344, 53248, 49152):
-                try:
-                    r = paced_realtime(api, synth, model, local_rank, b2, api.NN_MFMA, a.realtime_seconds)
-                except Exception as e:          # noqa: BLE001 — reported, not fatal
-                    runs.append({"streams": b2, "error": f"{type(e).__name__}: {e}"}); break
-                runs.append(r)
-                if r["deadline_misses"] == 0 and r["submit_call_ms"]["p99"] < 10.0 and r["finished_behind_schedule_ms"] < 10.0:
-                    ok = b2; break
-            res["realtime"] = {"paced_runs": runs, "realtime_streams_p99": ok,
-                               "contract": "one 480-sample frame per stream every 10 ms (reference src/main.cpp:30-39), frames arriving on the "
-                                           "host on a 10.000 ms clock, pipelined host path, zero deadline misses over the run"}
-            if "sustained" in res and res["sustained"].get("frame_ms_p99") is not None:
-                res["realtime"]["device_resident_frame_ms_p99_at_65536"] = res["sustained"]["frame_ms_p99"]
+            res["dsp_roofline"] = dsp_roofline(kt, B, tag, periods)
+        res.update(fields)                       # numa, sustained_ranks, realtime_ranks, realtime_all_ranks, cpu_baseline: the same keys at any N
+        if sustained is not None:
+            res["sustained"] = sustained
+        if capacity is not None:
+            res["realtime"] = capacity
+            res["realtime_streams_p99"] = capacity["realtime_streams_p99"]
+            if sustained is not None and sustained.get("frame_ms_p99") is not None:
+                res["realtime"]["device_resident_frame_ms_p99_at_65536"] = sustained["frame_ms_p99"]
+        elif fields.get("realtime_all_ranks"):
+            agg = fields["realtime_all_ranks"]
+            res["realtime_streams_p99"] = agg.get("streams_total") if agg.get("all_ranks_met_every_deadline") else None
+        # The headline tiles 64 distinct streams over the batch; this leg times the same steps on 65 536 streams that are all
+        # different (generated on the device), so the data-dependent branches of the pitch kernel see a real mix.
+        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_distinct):
+            try:
+                res["distinct_streams"] = distinct_streams_leg(api, torch, ctx, dev, B, K, W)
+                res["distinct_streams"]["headline_ms_per_step_for_comparison"] = res["ms_per_step"]
+                if kt:
+                    res["distinct_streams"]["headline_kernels_ms"] = {k: v["ms_avg"] for k, v in res["kernels"].items() if v["launches"]}
+            except Exception as e:              # noqa: BLE001 — reported, not fatal
+                res["distinct_streams"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
         # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
         # Only with the default headline workload at N = 1; a failure here never costs the headline line.

@@ -143,7 +143,16 @@ int pn_process_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float 
 int pn_submit_host_f32(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr);
 int pn_submit_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr);
 int pn_host_wait(pn_ctx *ctx);               /* every submitted frame delivered */
+/* Non-blocking: how many submitted frames have been DELIVERED (output copy complete) so far; -1 on error.  For callers on a
+   real-time clock that timestamp each frame's delivery between arrivals (reference contract: src/main.cpp:30-39). */
+int64_t pn_host_frames_delivered(pn_ctx *ctx);
 void *pn_host_alloc(size_t bytes);           /* pinned host memory (hipHostMalloc); NULL on failure */
+/* One host feeding several GPUs: bind the CALLING THREAD to the CPUs of the NUMA node `device` hangs off (sysfs
+   /sys/bus/pci/devices/<bdf>/numa_node) — call it in the thread that will own the device BEFORE pn_ctx_create / pn_host_alloc,
+   so that first touch places its pinned buffers next to that GPU.  Returns the node (>= 0) when bound, -1 when the affinity
+   was left alone; msg (optional) receives one line saying what was done or why not.  Never fatal.  (The reference's
+   fan-out, utils/run.sh:49,65,99, places nothing.) */
+int pn_bind_thread_to_device_numa(int device, char *msg, size_t msg_bytes);
 void pn_host_free(void *p);
 int pn_ctx_synchronize(pn_ctx *ctx);
 
@@ -179,7 +188,8 @@ int pn_ctx_reset_profile(pn_ctx *ctx);
 
 /* Debug tap (tests/tools): copy an internal device buffer to the host; which = 0 feat, 1 c1ring,
    2 c2ring, 3 c2out, 4..7 gru1..gb (ping-pong pair), 8 rb, 9 g|r, 10 look-ahead spectra ring, 11 comb-filtered
-   spectrum, 12 history ring.  Returns bytes copied or -1. */
+   spectrum, 12 history ring, 13 the pitch period the last frame's comb filter used (int32 per stream).  Returns bytes copied
+   or -1. */
 long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_bytes);
 /* Launch-refusal hooks (tests).  A network launcher that is asked for a geometry its software pipeline cannot run returns
    an error WITHOUT launching and the frame fails: pn_process_* / pn_submit_host_* / pn_ctx_compute_rnn_host return -1 with

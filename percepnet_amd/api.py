@@ -67,6 +67,8 @@ def load_library():
     for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_host_wait.argtypes = [_vp]
+    L.pn_host_frames_delivered.argtypes = [_vp]
+    L.pn_host_frames_delivered.restype = ctypes.c_int64
     L.pn_host_alloc.argtypes = [ctypes.c_size_t]
     L.pn_host_alloc.restype = _vp
     L.pn_host_free.argtypes = [_vp]

@@ -5,6 +5,7 @@
 // dropped, main.cpp:32-33); with a single pair ./feature_test.raw gets 68 floats per frame.
 //
 //   percepnet_run [--model model.pnw] [--strict | --x3] [--postfilter] [--slots N] [--device N | --devices 0,1,..|all]
+//                 [--no-numa] [--verbose]
 //                 in0.pcm out0.pcm [in1.pcm out1.pcm ...]
 //
 // --slots N: at most N concurrent streams per device; further pairs wait and take over the slot of a pair that has ended
@@ -14,7 +15,9 @@
 // Multi-GPU: streams are independent, so the pairs are cut into contiguous balanced shards, one per
 // device; every device gets its own host thread, its own context (a replica of the weights and tables) and its own
 // pinned buffers, and the threads never talk to each other — the one-process counterpart of the reference's shell
-// fan-out (utils/run.sh:49,65,99).  No collective is involved.
+// fan-out (utils/run.sh:49,65,99).  No collective is involved.  Each device's thread binds itself to the CPUs of that GPU's NUMA
+// node before it creates its context and pinned buffers (pn_bind_thread_to_device_numa; --no-numa leaves the affinity alone,
+// --verbose prints the binding).
 #include "../../include/percepnet_hip.h"
 #include "pn_cli_util.h"
 #include <stdio.h>
@@ -50,10 +53,18 @@ struct ShardRes {
 // queue: when the pair playing in a slot runs out of input, the slot is re-initialised on the device
 // (pn_ctx_reset_streams = rnnoise_destroy + rnnoise_create of the reference, denoise.cpp:252-280,326-331) and the next
 // waiting pair starts there on the following frame, while the other slots keep running.
+static bool g_numa = true, g_verbose = false;
 static void run_shard(Shard *sh, const pn_model *m, char **paths, int nn_mode, int postfilter, bool tap, int n_slots) {
   const int P = sh->count, B = n_slots > 0 && n_slots < P ? n_slots : P;
   auto fail = [&](int rc, const std::string &msg) { sh->rc = rc; sh->err = msg; };
   ShardRes R;
+  // this thread owns the device from here on: run on the CPUs of the GPU's NUMA node BEFORE the context and the pinned
+  // buffers exist (first touch places them), so that N threads feeding N GPUs do not all pull through one socket
+  if (g_numa) {
+    char msg[256];
+    pn_bind_thread_to_device_numa(sh->device, msg, sizeof(msg));
+    if (g_verbose) fprintf(stderr, "percepnet_run: %s\n", msg);
+  }
   R.cx = pn_ctx_create(m, sh->device, B, nn_mode, NULL);
   pn_ctx *cx = R.cx;
   if (!cx) return fail(3, std::string("pn_ctx_create: ") + pn_last_error());
@@ -136,6 +147,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[ai], "--strict")) nn_mode = PN_NN_STRICT;      // reference-order network, bit-exact to the CPU path
     else if (!strcmp(argv[ai], "--x3")) nn_mode = PN_NN_MFMA_X3;         // split-precision network (same +-1 LSB bound, ~2x the rate)
     else if (!strcmp(argv[ai], "--postfilter")) postfilter = 1;      // optional envelope post-filter (denoise.cpp:216-250)
+    else if (!strcmp(argv[ai], "--no-numa")) g_numa = false;         // leave the host threads' CPU affinity alone
+    else if (!strcmp(argv[ai], "--verbose")) g_verbose = true;       // one line per device: its NUMA binding
     else if (!strcmp(argv[ai], "--slots") && ai + 1 < argc) n_slots = atoi(argv[++ai]);   // concurrent streams per device: pairs queue for them
     else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) devices.assign(1, atoi(argv[++ai]));
     else if (!strcmp(argv[ai], "--devices") && ai + 1 < argc) {

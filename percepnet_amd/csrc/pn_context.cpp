@@ -985,6 +985,63 @@ extern "C" int pn_host_wait(pn_ctx *c) {
   PN_ON_DEVICE(c);
   return pipe_drain(c);
 }
+// Frames of the pipelined host path whose output copy has landed in the caller's buffer (non-blocking: event queries on the
+// at most two frames in flight; delivery is in order).  A caller on a real-time clock polls this between arrivals to
+// timestamp each frame's delivery (bench.py: arrival-to-delivery latency), which the blocking pn_submit_host_* cannot show.
+extern "C" int64_t pn_host_frames_delivered(pn_ctx *c) {
+  if (!c) { pn_set_error("NULL argument"); return -1; }
+  pn_ctx::Pipe &P = c->pipe;
+  if (!P.init || P.submitted == 0) return 0;
+  DeviceGuard _dg(c->device);
+  if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", c->device); return -1; }
+  int64_t done = P.submitted >= 2 ? P.submitted - 2 : 0;     // everything older than the two newest was waited for by a submit
+  for (int64_t f = done; f < P.submitted; f++) {
+    const hipError_t e = hipEventQuery(P.delivered[f & 1]);
+    if (e == hipSuccess) done = f + 1;
+    else { if (e != hipErrorNotReady) { pn_set_error("hipEventQuery failed: %s", hipGetErrorString(e)); return -1; } (void)hipGetLastError(); break; }
+  }
+  return done;
+}
+// NUMA placement of a host thread that feeds one device: bind the CALLING THREAD to the CPUs of the NUMA node the device hangs
+// off (read from /sys/bus/pci/devices/<bdf>/numa_node), BEFORE it allocates its pinned buffers — first touch then places
+// them next to the GPU's root port.  Returns the node (>= 0) when bound, -1 when nothing was changed (msg says why: no
+// affinity reported, sysfs unreadable, ...).  Never an error for the caller: an unbound thread is merely slower.
+#include <sched.h>
+extern "C" int pn_bind_thread_to_device_numa(int device, char *msg, size_t msg_bytes) {
+#define PN_SAY(...) do { if (msg && msg_bytes) snprintf(msg, msg_bytes, __VA_ARGS__); } while (0)
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) { (void)hipGetLastError(); PN_SAY("device %d: no PCI bus id", device); return -1; }
+  for (char *p = bdf; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs spells it lower-case
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen(path, "r");
+  int node = -1;
+  if (!f || fscanf(f, "%d", &node) != 1) { if (f) fclose(f); PN_SAY("device %d (%s): %s unreadable", device, bdf, path); return -1; }
+  fclose(f);
+  if (node < 0) { PN_SAY("device %d (%s): the platform reports no NUMA affinity (numa_node = -1)", device, bdf); return -1; }
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  char list[4096] = {0};
+  if (!f || !fgets(list, sizeof(list), f)) { if (f) fclose(f); PN_SAY("device %d (%s): node %d has no cpulist", device, bdf, node); return -1; }
+  fclose(f);
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) { PN_SAY("sched_getaffinity failed"); return -1; }
+  int n = 0;
+  for (char *p = list; *p && *p != '\n';) {              // "0-3,8,10-11"
+    char *e; const long lo = strtol(p, &e, 10); long hi = lo;
+    if (e == p) break;
+    if (*e == '-') { p = e + 1; hi = strtol(p, &e, 10); }
+    for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); n++; }
+    p = (*e == ',') ? e + 1 : e;
+    if (*e != ',') break;
+  }
+  if (!n) { PN_SAY("device %d (%s): node %d has no CPU inside this thread's affinity mask", device, bdf, node); return -1; }
+  if (sched_setaffinity(0, sizeof(want), &want) != 0) { PN_SAY("device %d (%s): sched_setaffinity failed", device, bdf); return -1; }
+  PN_SAY("device %d (%s): thread bound to the %d CPUs of NUMA node %d", device, bdf, n, node);
+  return node;
+}
+#undef PN_SAY
 extern "C" void *pn_host_alloc(size_t bytes) {
   void *p = NULL;
   if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { pn_set_error("hipHostMalloc(%zu) failed", bytes); return NULL; }
@@ -1075,7 +1132,8 @@ extern "C" int pn_ctx_get_rnn_state_host(pn_ctx *c, float *conv1, float *conv2, 
 
 // Debug tap (tests/tools only): copy an internal device buffer to the host.
 // which: 0 feat[B][128], 1 c1ring[5][B][128], 2 c2ring[3][B][512], 3 c2out[B][512],
-//        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68].  Returns the byte count.
+//        4..7 gru[i][2][B][512], 8 rb[2][B][128], 9 gr[B][68], 10 look-ahead spectra ring, 11 comb-filtered spectrum,
+//        12 history ring, 13 last_period int32 [B].  Returns the byte count.
 extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long long max_bytes) {
   if (!c || !dst) return -1;
   const size_t B = c->B, Bp = c->Bp;
@@ -1091,6 +1149,7 @@ extern "C" long long pn_ctx_debug_copy(pn_ctx *c, int which, void *dst, long lon
     case 10: src = c->yring; n = 6 * B * PN_SPEC_BINS * sizeof(float2); break;     // look-ahead spectra ring [6][B][400]
     case 11: src = c->Ps; n = B * PN_SPEC_BINS * sizeof(float2); break;            // comb-filtered spectrum [B][400]
     case 12: src = c->hist; n = B * PN_HIST_STRIDE * 4; break;                     // history ring
+    case 13: src = c->last_period; n = B * 4; break;                               // pitch period of the last frame, int32 [B]
     default: pn_set_error("bad debug buffer id"); return -1;
   }
   if ((long long)n > max_bytes) { pn_set_error("debug buffer needs %zu bytes", n); return -1; }

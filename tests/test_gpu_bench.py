@@ -23,8 +23,20 @@ def _bench(*args):
 
 
 def test_single_rank_line_has_measured_parity_and_roofline():
-    r = _bench("--streams", "2048", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--sustained-seconds", "0.3")
+    r = _bench("--streams", "2048", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--sustained-seconds", "0.3", "--realtime-seconds", "0.6")
     assert r["n_gpus"] == 1 and len(r["ranks"]) == 1
+    # fe_spec_out's algorithmic bytes follow from the run's own pitch periods (the worst case is kept beside them)
+    so = r["dsp_roofline"]["fe_spec_out"]
+    assert 60 <= so["pitch_period_mean"] <= 768 and so["algorithmic_bytes"] <= so["algorithmic_bytes_worst_case"]
+    assert abs(so["algorithmic_bytes"] - 2048 * (so["comb_window_bytes_mean"] + 3200 + 288 + 3200 + 512 + 4)) < 2048
+    # the per-rank legs and the NUMA record exist at N = 1 too (the same keys at any N)
+    assert len(r["numa"]) == 1 and "numa_node" in r["numa"][0] and r["numa"][0]["pci"].count(":") == 2
+    assert len(r["sustained_ranks"]) == 1 and len(r["realtime_ranks"]) == 1
+    rt = r["realtime_ranks"][0]
+    assert rt["streams"] == 2048 and rt["frames"] == 60 and rt["deadline_misses"] == 0 and rt["met_contract"] is True
+    assert 0 < rt["delivery_latency_ms"]["p50"] <= rt["delivery_latency_ms"]["p99"] <= 20.0
+    assert r["realtime_all_ranks"]["all_ranks_met_every_deadline"] is True and r["realtime_streams_p99"] == 2048
+    assert "value_note" in r
     assert r["config"]["distributed"].startswith("none")
     assert r["sustained"]["steps"] >= 8 and r["sustained"]["seconds"] >= 0.3 and r["sustained"]["value"] > 0
     assert r["config"]["kernel_families"]["gru"] == "batch" and r["config"]["kernel_families"]["dense"] == "small"   # 2048 streams
@@ -58,6 +70,9 @@ def test_paced_real_time_run_through_the_pipelined_host_path():
     assert r["frames"] == 60 and r["streams"] == 4096
     assert r["deadline_misses"] == 0 and r["submit_call_ms"]["p99"] < 5.0 and r["finished_behind_schedule_ms"] < 10.0
     assert 0 < r["serial_host_call_ms"] < 10.0
+    # arrival-to-delivery latency per frame (polled between arrivals), not only back-pressure of the submit call
+    assert r["delivery_latency_ms"]["frames"] == 60 and 0 < r["delivery_latency_ms"]["p50"] <= r["delivery_latency_ms"]["max"] < 20.0
+    assert r["frames_delivered_late"] == 0 and r["met_contract"] is True
 
 
 def test_split_precision_and_fp16_lines():
@@ -77,11 +92,35 @@ def test_split_precision_and_fp16_lines():
 
 
 def test_two_ranks_self_launched():
-    r = _bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "1024", "--steps", "5", "--warmup", "2")
+    r = _bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--streams", "1024", "--steps", "5", "--warmup", "2",
+               "--sustained-seconds", "0.3", "--realtime-seconds", "0.6")
     assert r["n_gpus"] == 2 and [x["rank"] for x in r["ranks"]] == [0, 1]
     assert all(x["stream_frames"] == 1024 * 5 for x in r["ranks"])
     assert abs(r["frames_per_s"] - 2 * 1024 * 5 / (r["ms_per_step"] * 5e-3)) < 1e-3 * r["frames_per_s"]
-    assert "cpu_baseline" not in r                       # only at N = 1
+    _complete_multi_rank_record(r, 2, 1024)
+
+
+def _complete_multi_rank_record(r, n, streams):
+    """Round-4 verdict item 3: an N > 1 line is a COMPLETE record — the CPU baseline (timed once by the launcher parent), one
+    sustained and one paced real-time object per rank with their aggregate, and each rank's NUMA placement."""
+    assert r["cpu_baseline"]["kind"] in ("reference", "port") and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] >= 1
+    assert [x["rank"] for x in r["numa"]] == list(range(n)) and all("numa_node" in x and "bound" in x for x in r["numa"])
+    assert [x["rank"] for x in r["sustained_ranks"]] == list(range(n)) and all(x["ms_per_step"] > 0 for x in r["sustained_ranks"])
+    assert [x["rank"] for x in r["realtime_ranks"]] == list(range(n))
+    for x in r["realtime_ranks"]:
+        assert x["streams"] == streams and x["frames"] == 60 and "deadline_misses" in x and x["delivery_latency_ms"]["frames"] == 60
+    agg = r["realtime_all_ranks"]
+    assert agg["streams_total"] == n * streams and len(agg["deadline_misses_per_rank"]) == n
+    assert agg["deadline_misses_total"] == sum(x["deadline_misses"] for x in r["realtime_ranks"])
+
+
+def test_world_of_one_through_rccl_carries_the_same_keys():
+    """The same record through RCCL ("nccl") on the hardware this box has: `--force-dist` = one rank launched by
+    torch.distributed.run, the CPU baseline handed over by the launcher parent, the per-rank legs gathered with
+    all_gather_object over RCCL."""
+    r = _bench("--force-dist", "--streams", "1024", "--steps", "5", "--warmup", "2", "--sustained-seconds", "0.3", "--realtime-seconds", "0.6", "--no-parity")
+    assert r["config"]["distributed"] == "torch.distributed nccl world 1"
+    _complete_multi_rank_record(r, 1, 1024)
 
 
 def test_world_of_one_runs_the_rccl_path():

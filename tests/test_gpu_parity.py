@@ -336,9 +336,13 @@ def test_cli_percepnet_run_matches_reference_cli_contract(blob, oracle, tmp_path
     args = []
     for i, x in enumerate(ins):
         (tmp_path / f"i{i}.pcm").write_bytes(x.tobytes()); args += [f"i{i}.pcm", f"o{i}.pcm"]
-    r = subprocess.run([exe, "--model", "m.pnw", "--strict", "--devices", "0,0"] + args, cwd=tmp_path, capture_output=True,
+    r = subprocess.run([exe, "--model", "m.pnw", "--strict", "--verbose", "--devices", "0,0"] + args, cwd=tmp_path, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr
+    # every device thread places itself on its GPU's NUMA node before it allocates (or says why it could not): one line each
+    assert r.stderr.count("percepnet_run: device 0 (") == 2, r.stderr
+    assert all(("thread bound to the" in l) or ("NUMA" in l) or ("unreadable" in l) or ("cpulist" in l) or ("affinity" in l)
+               for l in r.stderr.splitlines() if l.startswith("percepnet_run: device")), r.stderr
     for i, x in enumerate(ins):
         assert np.array_equal(np.fromfile(tmp_path / f"o{i}.pcm", np.int16), oracle.run_pcm(x)[0]), i
     for bad in ("0,7", "0,,0", "0,", "x"):     # not a visible ordinal / an empty element (never read as device 0) / not a number

@@ -99,3 +99,61 @@ def test_bench_launches_its_own_ranks():
     # message; the agent's failure report names every rank it launched
     assert 1 <= out.stderr.count("bench.py needs a GPU") <= 2, out.stderr[-2000:]
     assert "local_rank: 0" in out.stderr and "local_rank: 1" in out.stderr, out.stderr[-2000:]
+
+
+FIELDS_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    from percepnet_amd import sharding
+    dist = sharding.init_ranks("gloo", 2)
+    rank, local_rank, world = sharding.launched_world()
+    cpu = sharding.cpu_baseline_handoff(lambda: {"value": -1, "kind": "computed by rank 0"}, world, rank)
+    numa = sharding.numa_bind_for_device("0000:%%02x:00.0" %% (0x10 + local_rank), sysfs_root=sys.argv[1], bind=False)
+    rt = {"streams": 100 + rank, "deadline_misses": rank, "met_contract": rank == 0, "delivery_latency_ms": {"p99": 12.0 + rank}}
+    sus = {"ms_per_step": 9.5 + rank}
+    f = sharding.multi_rank_fields(dist, cpu, numa, sus, rt)
+    if rank == 0:
+        print(json.dumps(f))
+    sharding.barrier(dist)
+    dist.destroy_process_group()
+""")
+
+
+def test_the_two_rank_line_is_a_complete_record(tmp_path):
+    """Round-4 verdict item 3: an N > 1 line must carry cpu_baseline (timed once by the launcher parent and handed to
+    rank 0), one paced real-time and one sustained object PER RANK plus their aggregate, and where each rank's host memory
+    lives (numa) — through the very functions bench.py uses (sharding.spawn_with_cpu_baseline, cpu_baseline_handoff,
+    numa_bind_for_device, multi_rank_fields), at world_size 2 on gloo with a fake sysfs tree."""
+    sysfs = tmp_path / "sys"
+    for k, node in ((0x10, 0), (0x11, 1)):
+        d = sysfs / "bus/pci/devices" / ("0000:%02x:00.0" % k); d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        n = sysfs / "devices/system/node" / f"node{node}"; n.mkdir(parents=True)
+        (n / "cpulist").write_text("0-3,8\n" if node == 0 else "4-7,9-10\n")
+    script = tmp_path / "fields_worker.py"
+    script.write_text(FIELDS_WORKER % ROOT)
+    cmd = [sys.executable, "-c",
+           "import sys; sys.path.insert(0, %r); from percepnet_amd import sharding; "
+           "sys.exit(sharding.spawn_with_cpu_baseline(2, %r, [%r], lambda: {'value': 33.7, 'kind': 'timed by the launcher parent'}))"
+           % (ROOT, str(script), str(sysfs))]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    f = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert f["cpu_baseline"] == {"value": 33.7, "kind": "timed by the launcher parent"}      # the parent's, not recomputed
+    assert [n["numa_node"] for n in f["numa"]] == [0, 1] and [n["cpus"] for n in f["numa"]] == [5, 6]
+    assert [n["pci"] for n in f["numa"]] == ["0000:10:00.0", "0000:11:00.0"]
+    assert [r["streams"] for r in f["realtime_ranks"]] == [100, 101]
+    agg = f["realtime_all_ranks"]
+    assert agg["streams_total"] == 201 and agg["deadline_misses_per_rank"] == [0, 1] and agg["all_ranks_met_every_deadline"] is False
+    assert agg["delivery_latency_ms_p99_worst_rank"] == 13.0
+    assert [s["ms_per_step"] for s in f["sustained_ranks"]] == [9.5, 10.5]
+
+
+def test_numa_binding_reports_instead_of_failing(tmp_path):
+    from percepnet_amd import sharding
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    r = sharding.numa_bind_for_device("0000:aa:00.0", sysfs_root=str(tmp_path))
+    assert r["bound"] is False and "no numa_node" in r["why"]
+    d = tmp_path / "bus/pci/devices/0000:aa:00.0"; d.mkdir(parents=True); (d / "numa_node").write_text("-1\n")
+    r = sharding.numa_bind_for_device("0000:aa:00.0", sysfs_root=str(tmp_path))
+    assert r["numa_node"] == -1 and r["bound"] is False and "no NUMA affinity" in r["why"]
