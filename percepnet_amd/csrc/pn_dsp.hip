@@ -101,6 +101,8 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
     // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian extension + 1/960 of
     // inverse_transform (306-317).  Input i of the transform is bin k = i (i <= 480) or 960 - i (conjugated); bins >= 400
     // are exactly 0 (interp_band_gain never writes them).  Lane l < 60, butterfly c, input j: i = 4l + c + 240j.
+    // (round 5: a two-register-set software pipeline over the four butterflies — the spectra of c + 1 requested before the
+    // arithmetic of c — unrolls to 27 spilled registers at four waves per SIMD: 0.296 vs 0.250 ms, profiles/r05_front_end_variants.log)
     if (lane < 60) {
       const float2 *Xs = Xspec + (size_t)s * PN_SPEC_BINS, *Ps = Pspec + (size_t)s * PN_SPEC_BINS;
 #pragma unroll 1

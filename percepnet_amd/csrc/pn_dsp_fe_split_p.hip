@@ -36,6 +36,9 @@
 #ifndef PN_FP_DS_DPP
 #define PN_FP_DS_DPP 1                   // pitch_downsample: x[4m - 1] from the neighbouring lane (row rotate) instead of a scalar load
 #endif
+#ifndef PN_FP_DPP_ASM
+#define PN_FP_DPP_ASM 2                  // group-uniform recurrences: DPP adds from inline assembly (no hazard padding on the accumulator)
+#endif
 #ifndef PN_FP_COARSE_PK
 #define PN_FP_COARSE_PK 1                // coarse cross-correlation on packed f32 instructions (0: the scalar round-4 loop)
 #endif
@@ -64,6 +67,33 @@ __device__ __forceinline__ float fp_bc(float v) {
 // a product whose multiply carries a DPP operand, kept out of the SLP vectoriser's reach: paired into a v_pk_mul_f32 the
 // DPP operand would have to be materialised by a v_mov_b32_dpp first
 __device__ __forceinline__ float fp_mul_dpp(float dpp, float b) { float p = dpp * b; asm("" : "+v"(p)); return p; }
+// acc + (the value lane n of the row holds in v) / acc - (...), as ONE DPP instruction WITHOUT wait states in front of it.
+// Written in C++ (acc + fp_bc<n>(v)) the compiler emits the same v_add_f32_dpp but pads every DEPENDENT chain step with
+// s_nop: LLVM's hazard recogniser applies "VALU writes a VGPR -> a DPP instruction reads it: 2 wait states" to EVERY register
+// a DPP instruction reads, also the plain second operand (the running sum), and a step of these recurrences then costs 14
+// ticks instead of ~5 (tools/probes/dpp_chain_probe.hip).  The hazard concerns the operand that goes through the DPP
+// cross-lane path — here v, formed long before the chain starts (FP_DPP_SETTLE separates it from its producer) — not the
+// forwarded accumulator: the outputs are bit-identical with the padding removed (every parity test; hash of tools/fp_variants.py).
+#if PN_FP_DPP_ASM
+template <int n>
+__device__ __forceinline__ float fp_add_bc(float acc, float v) {
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(acc), "n"(n & 15));
+  return r;
+}
+template <int n>
+__device__ __forceinline__ float fp_sub_bc(float acc, float v) {       // acc - bc(v): v_subrev computes src1 - src0
+  float r;
+  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(acc), "n"(n & 15));
+  return r;
+}
+// two wait states between the VALU instructions that formed the DPP operands (+v: after them) and the first DPP read
+#define FP_DPP_SETTLE(...) asm volatile("s_nop 1" : __VA_ARGS__)
+#else
+template <int n> __device__ __forceinline__ float fp_add_bc(float acc, float v) { return acc + fp_bc<n>(v); }
+template <int n> __device__ __forceinline__ float fp_sub_bc(float acc, float v) { return acc - fp_bc<n>(v); }
+#define FP_DPP_SETTLE(...) do {} while (0)
+#endif
 #define FP_REP12(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define FP_REP16(M) FP_REP12(M) M(12) M(13) M(14) M(15)
 
@@ -181,6 +211,7 @@ __device__ __forceinline__ void fp_chain2_pairs(const float *a, const float *b1,
 // running-energy add + clamp per candidate and, only when some candidate of a group of four beats the current second
 // best (in any of the wave's streams), the cross-multiplied comparisons and selects on the (best, second best) state.
 __device__ __forceinline__ float fp_syy_next(float sy, float dd) { const float t = sy + dd; return (1 > t) ? 1 : t; }
+template <int n> __device__ __forceinline__ float fp_syy_next_bc(float sy, float dw) { const float t = fp_add_bc<n>(sy, dw); return (1 > t) ? 1 : t; }
 #define FP_FBP_STEP(nm_, sy_, idx_) do {                                                            \
     const float num = (nm_);                                                                        \
     const bool c1 = num * bd1 > bn1 * (sy_);                                                        \
@@ -192,9 +223,9 @@ __device__ __forceinline__ float fp_syy_next(float sy, float dd) { const float t
 // numerators from an opaque copy of nw_: were they the values of the test above, those would have to be materialised by
 // four v_mov_dpp on the hot path instead of riding inside the four multiplies.
 #define FP_SCAN_GROUP(g) do {                                                                       \
-    const float s0_ = Syy, s1_ = fp_syy_next(s0_, fp_bc<4 * (g)>(dw_)), s2_ = fp_syy_next(s1_, fp_bc<4 * (g) + 1>(dw_)), \
-                s3_ = fp_syy_next(s2_, fp_bc<4 * (g) + 2>(dw_));                                    \
-    Syy = fp_syy_next(s3_, fp_bc<4 * (g) + 3>(dw_));                                                \
+    const float s0_ = Syy, s1_ = fp_syy_next_bc<4 * (g)>(s0_, dw_), s2_ = fp_syy_next_bc<4 * (g) + 1>(s1_, dw_),     \
+                s3_ = fp_syy_next_bc<4 * (g) + 2>(s2_, dw_);                                        \
+    Syy = fp_syy_next_bc<4 * (g) + 3>(s3_, dw_);                                                    \
     const bool any_ = (fp_mul_dpp(fp_bc<4 * (g)>(nw_), bd1) > bn1 * s0_) | (fp_mul_dpp(fp_bc<4 * (g) + 1>(nw_), bd1) > bn1 * s1_) |   \
                       (fp_mul_dpp(fp_bc<4 * (g) + 2>(nw_), bd1) > bn1 * s2_) | (fp_mul_dpp(fp_bc<4 * (g) + 3>(nw_), bd1) > bn1 * s3_); \
     if (__ballot(any_)) {                                                                           \
@@ -220,6 +251,7 @@ __device__ __forceinline__ void fp_coarse_best_pitch(const float *xcorr, const f
     nreg[w] = (i < MAXP && xc > 0) ? x16 * x16 : __builtin_nanf("");
   }
   FP_FENCE();                                            // every operand read and formed before the serial part starts
+  FP_DPP_SETTLE("+v"(dreg[0]), "+v"(dreg[1]), "+v"(dreg[2]), "+v"(dreg[3]), "+v"(dreg[4]), "+v"(dreg[5]), "+v"(dreg[6]), "+v"(dreg[7]), "+v"(dreg[8]), "+v"(dreg[9]));
   float bn0 = -1.f, bn1 = -1.f, bd0 = 0.f, bd1 = 0.f; int bp0 = 0, bp1 = 1;
 #pragma unroll
   for (int w = 0; w < NW; w++) {
@@ -251,10 +283,11 @@ __device__ __forceinline__ float fp_fine_chain_scan(const float *a, const float 
     _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) (bv)[u_] = b[16 * (blk) + u_];              \
     if (scan) { const int i_ = 16 * (blk) + l, ic_ = i_ < MAXP ? i_ : MAXP - 1; (yav) = y[ic_ + LEN]; (ycv) = y[ic_]; } } while (0)
 #define FP_FS_STEP(u) acc = acc + fp_mul_dpp(fp_bc<u>(av_), bv_[u]);                               \
-    if (scan_) { capw_ = (l == (u)) ? Syy : capw_; Syy = fp_syy_next(Syy, fp_bc<u>(dw_)); }
+    if (scan_) { capw_ = (l == (u)) ? Syy : capw_; Syy = fp_syy_next_bc<u>(Syy, dw_); }
 #define FP_FS_MAC(av, bv, yav, ycv, blk, scan) do {                                               \
     const float av_ = (av); const float (&bv_)[16] = (bv); constexpr bool scan_ = (scan);         \
-    const float dw_ = scan_ ? (yav) * (yav) - (ycv) * (ycv) : 0.f; float capw_ = 0.f;             \
+    float dw_ = scan_ ? (yav) * (yav) - (ycv) * (ycv) : 0.f; float capw_ = 0.f;                   \
+    if (scan_) FP_DPP_SETTLE("+v"(dw_));                                                          \
     FP_REP16(FP_FS_STEP)                                                                          \
     if (scan_) capbuf[16 * (blk) + l] = capw_; } while (0)
   FP_FS_LOAD(a0, b0, ya0, yc0, 0, true);
@@ -531,9 +564,9 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         }
         // the energies stay scalar: paired by the SLP vectoriser their DPP operands would be materialised by a v_mov each
 #define FP_CO_ENERGY(u) {                                                                        \
-            SyyC = SyyC + fp_bc<u>(qc); asm("" : "+v"(SyyC));                                     \
-            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u)>(qf0) : fp_bc<2 * (u) - 16>(qf1)); asm("" : "+v"(SyyF)); \
-            SyyF = SyyF + ((u) < 8 ? fp_bc<2 * (u) + 1>(qf0) : fp_bc<2 * (u) - 15>(qf1)); asm("" : "+v"(SyyF)); }
+            SyyC = fp_add_bc<u>(SyyC, qc); asm("" : "+v"(SyyC));                                  \
+            SyyF = ((u) < 8 ? fp_add_bc<2 * (u)>(SyyF, qf0) : fp_add_bc<2 * (u) - 16>(SyyF, qf1)); asm("" : "+v"(SyyF)); \
+            SyyF = ((u) < 8 ? fp_add_bc<2 * (u) + 1>(SyyF, qf0) : fp_add_bc<2 * (u) - 15>(SyyF, qf1)); asm("" : "+v"(SyyF)); }
 #define FP_CO_WAIT(u) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(W[((u) + 5) % 12]), "+v"(W[((u) + 6) % 12]), "+v"(W[((u) + 7) % 12]))
 #define FP_CO_STEP(u) {                                                                         \
             if ((u) % 3 == 0 && (u)) FP_CO_WAIT(u);       /* releases the pairs the next three steps start to use */ \
@@ -550,7 +583,8 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
 #define FP_CO_TRIP(xcur_, xn_, j0_, jn_) {                                                        \
           fp_v2 (&xq_)[6] = xcur_;                                                                  \
           asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(W[5]), "+v"(W[6]), "+v"(W[7]), FP_PK_TIE_SET(xcur_), "+v"(yc), "+v"(yf)); \
-          const float qc = yc * yc, qf0 = yf.x * yf.x, qf1 = yf.y * yf.y;                           \
+          float qc = yc * yc, qf0 = yf.x * yf.x, qf1 = yf.y * yf.y;                                 \
+          FP_DPP_SETTLE("+v"(qc), "+v"(qf0), "+v"(qf1));                                            \
           FP_PK_OPERANDS(xn_, jn_);                                                                 \
           const unsigned yaj = ya + 8 * (j0_);                 /* byte address of y_lp4[11 l + j0] */ \
           FP_REP12(FP_CO_STEP) }
@@ -689,13 +723,31 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
             for (int w = 0; w < 4; w++) { pa[w] = an[w] * an[w]; qa[w] = cn[w] * cn[w]; }
             FP_YY_LOAD(blk < 5 ? blk + 1 : blk);       // next block's operands arrive under this block's chain
             FP_FENCE();
+            FP_DPP_SETTLE("+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
 #pragma unroll
             for (int w = 0; w < 4; w++) {
               const float pw_ = pa[w], qw_ = qa[w];
               float cw = 0.f;
-#define FP_YY_STEP(u) yy = yy + fp_bc<u>(pw_); yy = yy - fp_bc<u>(qw_); cw = (l == (u)) ? yy : cw;
+#if PN_FP_DPP_ASM >= 2
+              // the 16 steps of a block as ONE assembly statement (48 instructions, no padding between them: around single-
+              // instruction statements the compiler still leaves a wait state for an unknown producer); lane u of every
+              // row captures step u through a v_cndmask under a loop-invariant lane mask
+#define FP_YY_ASM(u, m) "v_add_f32_dpp %0, %2, %0 row_newbcast:" #u " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"        \
+                        "v_subrev_f32_dpp %0, %3, %0 row_newbcast:" #u " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"     \
+                        "v_cndmask_b32_e64 %1, %1, %0, %" #m "\n\t"
+#define FP_LM(u) (0x0001000100010001ull << (u))    /* lane u of each of the four rows */
+              asm(FP_YY_ASM(0, 4) FP_YY_ASM(1, 5) FP_YY_ASM(2, 6) FP_YY_ASM(3, 7) FP_YY_ASM(4, 8) FP_YY_ASM(5, 9) FP_YY_ASM(6, 10) FP_YY_ASM(7, 11)
+                  FP_YY_ASM(8, 12) FP_YY_ASM(9, 13) FP_YY_ASM(10, 14) FP_YY_ASM(11, 15) FP_YY_ASM(12, 16) FP_YY_ASM(13, 17) FP_YY_ASM(14, 18) FP_YY_ASM(15, 19)
+                  : "+v"(yy), "+v"(cw) : "v"(pw_), "v"(qw_), "s"(FP_LM(0)), "s"(FP_LM(1)), "s"(FP_LM(2)), "s"(FP_LM(3)), "s"(FP_LM(4)), "s"(FP_LM(5)),
+                    "s"(FP_LM(6)), "s"(FP_LM(7)), "s"(FP_LM(8)), "s"(FP_LM(9)), "s"(FP_LM(10)), "s"(FP_LM(11)), "s"(FP_LM(12)), "s"(FP_LM(13)),
+                    "s"(FP_LM(14)), "s"(FP_LM(15)));
+#undef FP_YY_ASM
+#undef FP_LM
+#else
+#define FP_YY_STEP(u) yy = fp_add_bc<u>(yy, pw_); yy = fp_sub_bc<u>(yy, qw_); cw = (l == (u)) ? yy : cw;
               FP_REP16(FP_YY_STEP)
 #undef FP_YY_STEP
+#endif
               ybuf[64 * blk + L * w + l] = cw;
             }
           }

@@ -36,15 +36,13 @@
 #define FS_THREADS (LANES * FS_WPB)
 #include "pn_fft960.h"
 #include "pn_launch.h"
+#include <stdlib.h>
 
 #ifndef PN_FS_WAVES_IN
 #define PN_FS_WAVES_IN 4                // waves per SIMD the register budget of spec_in is cut for (4: 128 registers)
 #endif
-#ifndef PN_FS_COMB_TAP_MAJOR
-#define PN_FS_COMB_TAP_MAJOR 1
-#endif
-#ifndef PN_FS_COMB_SETS
-#define PN_FS_COMB_SETS 3               // register sets of the comb filter's tap loads (one set = the four dwordx4 of a tap)
+#ifndef PN_FS_PREFETCH
+#define PN_FS_PREFETCH 1                 // spec_out: the next stream's period is requested one stream ahead
 #endif
 #ifndef PN_FS_WAVES_OUT
 #define PN_FS_WAVES_OUT 3               // spec_out (28 comb-tap loads + the X spectrum on top): 168 registers, three 4-wave blocks per CU
@@ -179,6 +177,53 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_IN) void pn_fe_spec_in_kern
   }
 }
 
+// Everything of a stream after its comb-filtered frame x[]: window + transform -> P, band energy Ep and correlation X.P,
+// features, silence flag (denoise.cpp:423-434, create_features 487-496).  X(t) is requested AFTER the transform: held across it
+// its 14 registers cost 11 spills at three waves per SIMD (measured: no gain).
+__device__ __forceinline__ void fs_spec_out_tail(const float4 *x, const float2 *__restrict__ Xr, float Ex, float Ey, int s, int l, float2 *F, float *C,
+                                                 const FsShared &SH, const FsLane &Z, const FsBands &B, const PnTables *__restrict__ T,
+                                                 float2 *__restrict__ Pspec, float *__restrict__ feat, int *__restrict__ silence, float *__restrict__ aux) {
+  fs_fft_p1(F, SH.win, Z, x, l);
+  float2 w[3][5];
+  fs_fft_p23<false>(F, T, l, w);
+  const float2 o2 = w[0][2];
+  float2 xv[FS_NBIN];
+#pragma unroll
+  for (int j = 0; j < FS_NBIN; j++) xv[j] = Xr[(j < 6) ? l + 64 * j : (l < 16 ? 384 + l : 0)];
+  float tp[FS_NBIN], tx[FS_NBIN];
+#pragma unroll
+  for (int j = 0; j < FS_NBIN; j++) {
+    const float2 P = j < 6 ? w[j % 3][j / 3] : o2;
+    if (j < 6 || l < 16) Pspec[(size_t)s * PN_SPEC_BINS + (j < 6 ? l + 64 * j : 384 + l)] = P;
+    float t = P.x * P.x; t += P.y * P.y; tp[j] = t;        // compute_band_energy's per-bin term (denoise.cpp:100-101)
+    float u = xv[j].x * P.x; u += xv[j].y * P.y; tx[j] = u;  // compute_band_corr's (136-137)
+  }
+  PN_WAVE_SYNC();
+  fs_bands_fill(C, B, tp, l);
+  fs_bands_fill(C + PN_BAND_LAYOUT_FLOATS, B, tx, l);
+  PN_WAVE_SYNC();
+  float sums[2];
+  fs_bands_sum<2>(C, B, l, sums);
+  const float Ep = sums[0];
+  float Exp = sums[1];
+  float *f = feat + (size_t)s * PN_FEAT_STRIDE;
+  if (l < PN_NB) {
+    // double island, denoise.cpp:427
+    Exp = (float)fmin(1.0, fmax(0.0, (double)Exp / sqrt(1e-15 + (double)(Ex * Ep))));
+    f[l] = Ey * 30;              // create_features (487-496)
+    f[PN_NB + l] = Exp * 30;
+    if (aux) { aux[(size_t)s * PN_AUX_STRIDE + l] = Ep; aux[(size_t)s * PN_AUX_STRIDE + PN_NB + l] = Exp; }
+  }
+  // silence = sum(Ex) < 0.1 (429-433): sequential sum over the 34 bands, in band order
+  {
+    float E = 0;
+#pragma unroll
+    for (int i = 0; i < PN_NB; i++) E += __shfl(Ex, i);
+    if (l == 0) silence[s] = ((double)E < 0.1) ? 1 : 0;
+  }
+  PN_WAVE_SYNC();
+}
+
 // ---- spectral-out: comb filter at the pitch period + window + FFT -> P, Ep, Exp, features ---------------------------------
 __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_kernel(
     const PnTables *__restrict__ T, int n_streams, int frame_t, int slot_w, int slot_r,
@@ -203,57 +248,31 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
   for (int k = 0; k < 7; k++) cw[k] = T->comb_hann[k];
   const int base_slot0 = (frame_t + 1) % PN_HIST_FRAMES;   // slot of logical frame 0 (oldest)
   const int lc = l < 60 ? l : 59;
+#if PN_FS_PREFETCH & 1
+  // the pitch period of a wave's NEXT stream is requested one stream ahead: otherwise every stream starts with two dependent
+  // memory round trips (the period, then the 28 tap loads whose addresses it decides) with nothing else in flight
+  int period_next = 0;
+  { const int s0 = blockIdx.x * FS_WPB + wave; if (s0 < n_streams) period_next = last_period[s0]; }
+#endif
   for (int s = blockIdx.x * FS_WPB + wave; s < n_streams; s += gridDim.x * FS_WPB) {
     const float *h = hist + (size_t)s * PN_HIST_STRIDE;
+#if PN_FS_PREFETCH & 1
+    const int pitch_index = period_next;
+    { const int sn = s + gridDim.x * FS_WPB; period_next = last_period[sn < n_streams ? sn : s]; }
+#else
     const int pitch_index = last_period[s];
+#endif
     int base_slot = base_slot0;
     asm volatile("" : "+v"(base_slot));              // keeps the 28 ring offsets below from being hoisted out of the stream loop
     const float2 *Xr = yring + ((size_t)slot_r * n_streams + s) * PN_SPEC_BINS;   // X(t)  = Y(t-5)
     const float Ex = l < PN_NB ? eyring[((size_t)slot_r * n_streams + s) * 36 + l] : 0.f;   // Ex(t) = Ey(t-5)
     const float Ey = l < PN_NB ? eyring[((size_t)slot_w * n_streams + s) * 36 + l] : 0.f;   // Ey of this frame
-#if PN_FS_COMB_TAP_MAJOR
-    // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240q .. +3, q = 0..3; one unaligned dwordx4
-    // load per tap and quarter (the ring carries an 8-sample mirror).
-    // TAP-MAJOR order: tap k reads the 960 contiguous samples [2400 - T k, +960) as four back-to-back loads, and tap
-    // k + 1 reads the same window shifted down by T — the 960 - T samples two consecutive taps share (T <= 768: every
-    // frame) are requested again four loads later, while their lines are still in the cache hierarchy next to this CU,
-    // instead of microseconds later from another half of the kernel as in the quarter-major order of rounds 3-4
-    // (FETCH_SIZE 30.2 KB per stream against 21 KB of union window + spectra: the overlaps were re-fetched through the
-    // fabric).  The sums are the reference's: per output sample the seven products are added in tap order k = -3 .. 3
-    // onto 0 (denoise.cpp:419-421); only the order in which INDEPENDENT outputs advance changes.  Three register sets:
-    // the loads of tap k + 2 are issued before the multiply-adds of tap k.
-    float4 x[4];
-    {
-      fe_f4u cs[PN_FS_COMB_SETS][4];
-      float pa[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) pa[q][c] = 0;
-#define FS_COMB_LOAD(set, kk) do {                                                                    \
-        const int tap0_ = 2400 - pitch_index * ((kk) - PN_COMB_M) + 4 * lc;                           \
-        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                 \
-          cs[set][q] = *reinterpret_cast<const fe_f4u *>(h + fe_ring(tap0_ + 240 * q, base_slot));     \
-      } while (0)
-#pragma unroll
-      for (int k0 = 0; k0 < PN_FS_COMB_SETS - 1; k0++) FS_COMB_LOAD(k0, k0);
-#pragma unroll
-      for (int kk = 0; kk < 7; kk++) {
-        if (kk + PN_FS_COMB_SETS - 1 < 7) FS_COMB_LOAD((kk + PN_FS_COMB_SETS - 1) % PN_FS_COMB_SETS, kk + PN_FS_COMB_SETS - 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int c = 0; c < 4; c++) pa[q][c] += cs[kk % PN_FS_COMB_SETS][q][c] * cw[kk];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef FS_COMB_LOAD
-#pragma unroll
-      for (int q = 0; q < 4; q++) x[q] = make_float4(pa[q][0], pa[q][1], pa[q][2], pa[q][3]);
-    }
-#else    // the quarter-major order of rounds 3-4 (kept for A/B measurements)
     // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240k .. +3, k = 0..3; one unaligned dwordx4
     // load per tap (the ring carries an 8-sample mirror).  Two k at a time: 14 loads in flight.
+    // Measured in round 5 (profiles/r05_fe_steady_state.log, r05_fetch_size_calibration.log): in steady state the windows
+    // two taps share ARE served once — 22.5 KB of traffic per stream against 21.8 KB of algorithmic bytes (mean period 446);
+    // a tap-major order with 8 .. 28 loads in flight moved 23.4 KB in the same time, a cross-stream pipeline at two waves
+    // per SIMD (all 28 windows of the next stream requested under the current stream's transform) was 35 % slower.
     float4 x[4];
     int bs = base_slot;
 #pragma unroll
@@ -280,48 +299,10 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
         x[k0 + q] = make_float4(p[0], p[1], p[2], p[3]);
       }
     }
-#endif
-    fs_fft_p1(F, SH.win, Z, x, l);
-    float2 w[3][5];
-    fs_fft_p23<false>(F, T, l, w);
-    const float2 o2 = w[0][2];
-    float2 xv[FS_NBIN];
-#pragma unroll
-    for (int j = 0; j < FS_NBIN; j++) xv[j] = Xr[(j < 6) ? l + 64 * j : (l < 16 ? 384 + l : 0)];
-    float tp[FS_NBIN], tx[FS_NBIN];
-#pragma unroll
-    for (int j = 0; j < FS_NBIN; j++) {
-      const float2 P = j < 6 ? w[j % 3][j / 3] : o2;
-      if (j < 6 || l < 16) Pspec[(size_t)s * PN_SPEC_BINS + (j < 6 ? l + 64 * j : 384 + l)] = P;
-      float t = P.x * P.x; t += P.y * P.y; tp[j] = t;        // compute_band_energy's per-bin term (denoise.cpp:100-101)
-      float u = xv[j].x * P.x; u += xv[j].y * P.y; tx[j] = u;  // compute_band_corr's (136-137)
-    }
-    PN_WAVE_SYNC();
-    fs_bands_fill(C, B, tp, l);
-    fs_bands_fill(C + PN_BAND_LAYOUT_FLOATS, B, tx, l);
-    PN_WAVE_SYNC();
-    float sums[2];
-    fs_bands_sum<2>(C, B, l, sums);
-    const float Ep = sums[0];
-    float Exp = sums[1];
-    float *f = feat + (size_t)s * PN_FEAT_STRIDE;
-    if (l < PN_NB) {
-      // double island, denoise.cpp:427
-      Exp = (float)fmin(1.0, fmax(0.0, (double)Exp / sqrt(1e-15 + (double)(Ex * Ep))));
-      f[l] = Ey * 30;              // create_features (487-496)
-      f[PN_NB + l] = Exp * 30;
-      if (aux) { aux[(size_t)s * PN_AUX_STRIDE + l] = Ep; aux[(size_t)s * PN_AUX_STRIDE + PN_NB + l] = Exp; }
-    }
-    // silence = sum(Ex) < 0.1 (429-433): sequential sum over the 34 bands, in band order
-    {
-      float E = 0;
-#pragma unroll
-      for (int i = 0; i < PN_NB; i++) E += __shfl(Ex, i);
-      if (l == 0) silence[s] = ((double)E < 0.1) ? 1 : 0;
-    }
-    PN_WAVE_SYNC();
+    fs_spec_out_tail(x, Xr, Ex, Ey, s, l, F, C, SH, Z, B, T, Pspec, feat, silence, aux);
   }
 }
+
 
 // ---- launchers --------------------------------------------------------------------------------------------------------
 static int fs_grid(int n_streams, int blocks_per_cu, int grid_cap) {
@@ -344,7 +325,7 @@ void pn_launch_fe_spec_out(hipStream_t st, const PnTables *T, int n_streams, int
                            int *silence, float *aux, int grid_cap) {
   const int frame_t = (int)(frame % PN_HIST_FRAMES), slot_w = (int)(frame % 6), slot_r = (int)((frame + 1) % 6);
   hipLaunchKernelGGL(pn_fe_spec_out_kernel, dim3(fs_grid(n_streams, PN_FS_WAVES_OUT, grid_cap)), dim3(FS_THREADS), 0, st, T, n_streams, frame_t, slot_w,
-                     slot_r, hist, yring, eyring, last_period, Ps, feat, silence, aux);
+                       slot_r, hist, yring, eyring, last_period, Ps, feat, silence, aux);
 }
 
 // The three phase kernels in sequence = pn_launch_frontend (same arguments, same results bit for bit).
