@@ -567,12 +567,13 @@ def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log)
                         f"{DELIVERY_DEADLINE_MS} ms after arrival and no schedule slip; a size passes when ALL its runs pass"}
 
 
-def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026):
+def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026, prime=12):
     """65 536 DISTINCT streams (round-4 verdict item 4): the headline tiles 64 pool streams over the batch, so the
     data-dependent paths of the pitch kernel see 64 behaviours.  Here every stream is synthesised on the device from its own
     parameters — a harmonic tone with its own fundamental (60-500 Hz, gliding), harmonic count, level (5 % near full scale, so
     the non-silent branch runs) and noise floor — and the same K steps are timed with per-kernel events."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
+    W = W + prime                                            # stream priming (one history ring) + warm-up, as in the headline
     T = K + W
     f0 = 60.0 + 440.0 * torch.rand(B, 1, device=dev, generator=g)
     glide = 1.0 + 0.2 * (torch.rand(B, 1, device=dev, generator=g) - 0.5)
@@ -608,7 +609,7 @@ def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026):
     kt = ctx.kernel_times()
     import numpy as np
     per = np.frombuffer(ctx.debug_copy(13, B).tobytes(), dtype=np.int32)
-    return {"streams": B, "distinct_streams": distinct, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 4),
+    return {"streams": B, "distinct_streams": distinct, "steps": K, "warmup": W - prime, "prime_frames": prime, "ms_per_step": round(1e3 * dt / K, 4),
             "value": round(B * K / dt / 100.0, 1), "unit": "streams",
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if v[1]},
             "pitch_period_of_last_frame": {"min": int(per.min()), "mean": round(float(per.mean()), 1), "max": int(per.max()),
@@ -617,12 +618,12 @@ def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026):
                     "and noise floor, 5 % near full scale), no two streams alike"}
 
 
-def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, traffic_tag):
+def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, traffic_tag, prime=12):
     """One of BASELINE's OTHER single-GPU configurations, timed the same way as the headline (W warm-up steps, K timed
     steps between synchronisations, inputs resident, no per-kernel events) and checked against the oracle on its own
     batch — reported under "other_configs", never as `value`.  A second, separately timed pass with per-kernel HIP
     events gives the configuration its own roofline object."""
-    T = K + W
+    T = prime + K + W
     P = min(B, 64)
     pool_np = synth.synth_batch(P, T, base_seed=synth.BASE_SEED + 104729)
     pool = torch.from_numpy(pool_np).to(dev)
@@ -633,17 +634,17 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
     out = torch.empty((B, FRAME), dtype=torch.int16, device=dev)
     ctx = api.Context(model, B, device=dev.index, nn_mode=nn_mode, stream=stream.cuda_stream)
     try:
-        for t in range(W):
+        for t in range(prime + W):                  # stream priming (one history ring) + warm-up
             ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for t in range(W, T):
+        for t in range(prime + W, T):
             ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        par = measure_parity(ctx, frames, pool_np, out, torch)
+        par = measure_parity(ctx, frames, pool_np, out, torch)     # leaves the context at the end of a replay of all T frames
         ctx.reset_profile(); ctx.set_profiling(True)
-        for t in range(min(T, 40)):
+        for t in range(T - min(K, 40), T):           # steady-state frames again, with per-kernel events
             ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
         torch.cuda.synchronize()
         ctx.set_profiling(False)
@@ -662,7 +663,7 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
             "unit": "streams", "ms_per_step": round(ms_step, 4), "frames_per_s": round(B * K / dt, 1),
             "max_abs_delta_vs_cpu_ref_lsb": par["max_abs_delta_vs_cpu_ref_lsb"], "max_abs_delta_gr": par["max_abs_delta_gr"],
             "pcm_samples_checked": par["pcm_samples_checked"], "replay_bit_identical": par["replay_of_timed_run_bit_identical"],
-            "kernel_families": desc,
+            "kernel_families": desc, "sclk_mhz_after": gpu_clock_mhz(),
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
             "dtype": DTYPE_OF_MODE[nn_mode],
             "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, 1, B * K / dt, traffic_tag=traffic_tag),
@@ -744,6 +745,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launched world, else 1")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prime", type=int, default=12,
+                    help="frames run during SETUP, before the warm-up: one history ring (12 frames).  A context fresh from the zero state is not the "
+                         "workload: until its history has filled, the pitch search returns the degenerate period 768 and the comb filter reads "
+                         "its largest window; the W warm-up and K timed steps then run on steady-state stream state")
     ap.add_argument("--streams", type=int, default=65536, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
@@ -810,9 +815,10 @@ def main():
     n_gpus = world
 
     B, K, W = a.streams, a.steps, a.warmup
+    PRIME = max(a.prime, 0)
     print(f"[bench] rank {rank}/{world} B={B} K={K} W={W} dist={'none' if dist is None else dist.get_backend()}",
           file=sys.stderr, flush=True)
-    T = K + W
+    T = PRIME + K + W
     blob = weights.default_blob(1234)
     model = api.Model(blob)
     # one explicit stream for torch AND the context: torch's default stream has handle 0, which pn_ctx_create reads as
@@ -841,7 +847,7 @@ def main():
     gr_buf = torch.empty((B, 68), dtype=torch.float32, device=dev) if os.environ.get("PN_BENCH_GR") else None
 
     def step(t):
-        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), gr_buf.data_ptr() if gr_buf is not None else None)
+        ctx.process_i16_dev(frames[PRIME + t].data_ptr(), out.data_ptr(), gr_buf.data_ptr() if gr_buf is not None else None)
 
     def before_timed():
         if not a.no_profile:
@@ -851,8 +857,10 @@ def main():
 
     # The inputs above were produced by torch kernels on `stream`, the context launches on the same stream: ordered.
     # The synchronise only keeps input generation out of the warm-up.
+    for t in range(PRIME):                                   # setup: fill the streams' history (not a timed or warm-up step)
+        ctx.process_i16_dev(frames[t].data_ptr(), out.data_ptr(), None)
     torch.cuda.synchronize()
-    print(f"[bench] inputs resident ({T} frames x {B} streams), state {ctx.device_bytes() / 2**30:.2f} GiB",
+    print(f"[bench] inputs resident ({T} frames x {B} streams, {PRIME} of them run as stream priming), state {ctx.device_bytes() / 2**30:.2f} GiB",
           file=sys.stderr, flush=True)
     dt = sharding.timed_steps(dist, step, W, K, torch.cuda.synchronize)
     ctx.set_profiling(False)
@@ -873,6 +881,45 @@ def main():
     parity = None
     if rank == 0 and not a.no_parity and not a.strict:
         parity = measure_parity(ctx, frames, pool_np, out, torch)
+
+
+    # ---- N = 1, headline workload: the side measurements run BEFORE the long sustained / paced legs (two minutes of full load
+    # leave the chip warmer and the latency-regime configuration, 1024 streams, is clock-sensitive: 0.39 vs 0.42 ms per frame) ---------
+    side = {}
+    if rank == 0:
+        # The headline tiles 64 distinct streams over the batch; this leg times the same steps on 65 536 streams that are all
+        # different (generated on the device), so the data-dependent branches of the pitch kernel see a real mix.
+        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_distinct):
+            try:
+                side["distinct_streams"] = distinct_streams_leg(api, torch, ctx, dev, B, K, W)
+                side["distinct_streams"]["headline_ms_per_step_for_comparison"] = round(1e3 * dt / K, 4)
+                if kt:
+                    side["distinct_streams"]["headline_kernels_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items() if v[1]}
+            except Exception as e:              # noqa: BLE001 — reported, not fatal
+                side["distinct_streams"] = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
+        # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
+        # Only with the default headline workload at N = 1; a failure here never costs the headline line.
+        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_other_configs or a.no_parity):
+            other = {}
+            for key, (b2, k2, w2, mode2, label, ttag) in {
+                    "configs[1]": (1024, 200, 20, api.NN_MFMA, "1024 concurrent streams, fp32 (small-batch kernel family)", "_1024"),
+                    "configs[4]": (65536, 20, 3, api.NN_MFMA_F16, "65536 concurrent streams, fp16 GEMM operands, fp32 accumulate/state/DSP", "_fp16"),
+                    # not a BASELINE config: the same fp32 network evaluated on the fp16 matrix cores with error compensation,
+                    # inside the fp32 MFMA mode's parity bounds (tests/test_gpu_x3.py); opt-in (`--x3`), never the headline `value`
+                    "split_precision_x3": (65536, 20, 3, api.NN_MFMA_X3, "65536 concurrent streams, fp32 network as fp16 hi+lo operand pairs (3 MFMA products), fp32 accumulate/state/DSP", "_x3"),
+            }.items():
+                try:
+                    other[key] = side_config(api, synth, torch, model, dev, stream, b2, k2, w2, mode2, label, ttag)
+                except Exception as e:          # noqa: BLE001 — reported, not fatal
+                    other[key] = {"workload": label, "error": f"{type(e).__name__}: {e}"}
+            side["other_configs"] = other
+            try:
+                side["drop_in_single_stream"] = drop_in_single_stream()
+                if cpu is not None and side["drop_in_single_stream"] and "ms_per_frame" in side["drop_in_single_stream"]:
+                    side["drop_in_single_stream"]["cpu_reference_ms_per_frame_one_core"] = round(1e3 / cpu["frames_per_s_one_core"], 4)
+            except Exception as e:              # noqa: BLE001
+                side["drop_in_single_stream"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- legs EVERY rank runs, side by side (one host feeding N GPUs), gathered like `ranks` -----------------------------
     # Sustained rate: the same step loop (no per-kernel events) for >= 5 s, next to the K-step figure — K = 20 steps
@@ -910,7 +957,7 @@ def main():
             "value_note": "`value` = stream-frames per second / 100 over the K timed steps (throughput expressed in 10 ms streams; it is "
                           "not a batch that ran); the deadline-PROVEN capacity is `realtime_streams_p99` (paced 10 ms clock, PCIe in the loop)",
             "frames_per_s": round(fps, 1),
-            "n_gpus": n_gpus, "steps": K, "warmup": W,
+            "n_gpus": n_gpus, "steps": K, "warmup": W, "prime_frames": PRIME,
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_OF_MODE[1 if a.strict else (2 if a.fp16 else (3 if a.x3 else 0))], "data": "synthetic",
@@ -954,39 +1001,7 @@ def main():
         elif fields.get("realtime_all_ranks"):
             agg = fields["realtime_all_ranks"]
             res["realtime_streams_p99"] = agg.get("streams_total") if agg.get("all_ranks_met_every_deadline") else None
-        # The headline tiles 64 distinct streams over the batch; this leg times the same steps on 65 536 streams that are all
-        # different (generated on the device), so the data-dependent branches of the pitch kernel see a real mix.
-        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_distinct):
-            try:
-                res["distinct_streams"] = distinct_streams_leg(api, torch, ctx, dev, B, K, W)
-                res["distinct_streams"]["headline_ms_per_step_for_comparison"] = res["ms_per_step"]
-                if kt:
-                    res["distinct_streams"]["headline_kernels_ms"] = {k: v["ms_avg"] for k, v in res["kernels"].items() if v["launches"]}
-            except Exception as e:              # noqa: BLE001 — reported, not fatal
-                res["distinct_streams"] = {"error": f"{type(e).__name__}: {e}"}
-        # BASELINE's other single-GPU configurations, so that they are timed by whoever runs this bench and not only by
-        # the builder: configs[1] (1024 streams, the latency regime) and configs[4] (fp16 operands, tolerance re-stated).
-        # Only with the default headline workload at N = 1; a failure here never costs the headline line.
-        if world == 1 and B == 65536 and not (a.fp16 or a.x3 or a.strict or a.no_other_configs or a.no_parity):
-            other = {}
-            for key, (b2, k2, w2, mode2, label, ttag) in {
-                    "configs[1]": (1024, 200, 20, api.NN_MFMA, "1024 concurrent streams, fp32 (small-batch kernel family)", "_1024"),
-                    "configs[4]": (65536, 20, 3, api.NN_MFMA_F16, "65536 concurrent streams, fp16 GEMM operands, fp32 accumulate/state/DSP", "_fp16"),
-                    # not a BASELINE config: the same fp32 network evaluated on the fp16 matrix cores with error compensation,
-                    # inside the fp32 MFMA mode's parity bounds (tests/test_gpu_x3.py); opt-in (`--x3`), never the headline `value`
-                    "split_precision_x3": (65536, 20, 3, api.NN_MFMA_X3, "65536 concurrent streams, fp32 network as fp16 hi+lo operand pairs (3 MFMA products), fp32 accumulate/state/DSP", "_x3"),
-            }.items():
-                try:
-                    other[key] = side_config(api, synth, torch, model, dev, stream, b2, k2, w2, mode2, label, ttag)
-                except Exception as e:          # noqa: BLE001 — reported, not fatal
-                    other[key] = {"workload": label, "error": f"{type(e).__name__}: {e}"}
-            res["other_configs"] = other
-            try:
-                res["drop_in_single_stream"] = drop_in_single_stream()
-                if cpu is not None and res["drop_in_single_stream"] and "ms_per_frame" in res["drop_in_single_stream"]:
-                    res["drop_in_single_stream"]["cpu_reference_ms_per_frame_one_core"] = round(1e3 / cpu["frames_per_s_one_core"], 4)
-            except Exception as e:              # noqa: BLE001
-                res["drop_in_single_stream"] = {"error": f"{type(e).__name__}: {e}"}
+        res.update(side)
         print(json.dumps(res), flush=True)
     ctx.close()
     model.close()

@@ -55,20 +55,23 @@ def load_library():
     L.pn_ctx_device_bytes.restype = ctypes.c_size_t
     L.pn_ctx_device_bytes.argtypes = [_vp]
     L.pn_ctx_describe.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
-    L.pn_ctx_weight_bytes.restype = ctypes.c_size_t
-    L.pn_ctx_weight_bytes.argtypes = [_vp]
+    if hasattr(L, "pn_ctx_weight_bytes"):
+        L.pn_ctx_weight_bytes.restype = ctypes.c_size_t
+        L.pn_ctx_weight_bytes.argtypes = [_vp]
     for name in ("pn_process_f32", "pn_process_i16", "pn_process_host_f32", "pn_process_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
-    for name in ("pn_process_f32_active", "pn_process_i16_active"):
-        getattr(L, name).argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]
-    L.pn_debug_check_launch.argtypes = [ctypes.c_int] * 4
-    L.pn_ctx_debug_inject_launch_failure.argtypes = [_vp, ctypes.c_int]
+    if hasattr(L, "pn_process_i16_active"):                 # (a round-4 library loaded through PERCEPNET_LIB for A/B timing has none of these)
+        for name in ("pn_process_f32_active", "pn_process_i16_active"):
+            getattr(L, name).argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]
+        L.pn_debug_check_launch.argtypes = [ctypes.c_int] * 4
+        L.pn_ctx_debug_inject_launch_failure.argtypes = [_vp, ctypes.c_int]
     for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_host_wait.argtypes = [_vp]
-    L.pn_host_frames_delivered.argtypes = [_vp]
-    L.pn_host_frames_delivered.restype = ctypes.c_int64
+    if hasattr(L, "pn_host_frames_delivered"):
+        L.pn_host_frames_delivered.argtypes = [_vp]
+        L.pn_host_frames_delivered.restype = ctypes.c_int64
     L.pn_host_alloc.argtypes = [ctypes.c_size_t]
     L.pn_host_alloc.restype = _vp
     L.pn_host_free.argtypes = [_vp]

@@ -48,7 +48,7 @@ def test_single_rank_line_has_measured_parity_and_roofline():
     assert isinstance(r["max_abs_delta_vs_cpu_ref_lsb"], int) and r["max_abs_delta_vs_cpu_ref_lsb"] <= 1
     assert r["max_abs_delta_gr"] <= 2e-5
     assert r["parity"]["replay_of_timed_run_bit_identical"] is True
-    assert r["parity"]["pcm_samples_checked"] == 64 * 9 * 480
+    assert r["prime_frames"] == 12 and r["parity"]["pcm_samples_checked"] == 64 * (12 + 9) * 480
     assert r["roofline"]["bound"] == "mfma" and 0 < r["roofline"]["frac"] < 1
     assert abs(r["value"] * 100 - r["frames_per_s"]) < 10
 

@@ -255,3 +255,4 @@ def test_a_refused_launch_fails_the_frame(model, mode):
     for t in range(3):
         assert np.array_equal(ctx.process_i16(pcm[:, t * 480:(t + 1) * 480])[0], good.process_i16(pcm[:, t * 480:(t + 1) * 480])[0])
     ctx.close(); good.close()
+

@@ -19,8 +19,22 @@ ap.add_argument("tag")
 ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "prof"))
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles"))
 ap.add_argument("--suffix", default="", help="configuration suffix of the output names: '' (headline), _1024, _fp16, _x3")
+ap.add_argument("--frames-total", type=int, default=0, help="frames the profiled bench ran (warm-up + steps); with --frames-keep: only the "
+                "launches of the LAST frames-keep frames of every (kernel, grid) are summarised — the steady state.  The history ring holds 12 "
+                "frames: the first frames of a run from the zero state filter at degenerate pitch periods (T = 768) and move more bytes")
+ap.add_argument("--frames-keep", type=int, default=0)
 a = ap.parse_args()
 SRC, out, tag, suf = a.src, a.out, a.tag, a.suffix
+
+
+def steady(rows):
+    """rows: [(dispatch id, value)] of one (kernel, grid) -> the values of the last frames-keep frames (all, if not asked)"""
+    rows = sorted(rows)
+    if a.frames_total > 0 and 0 < a.frames_keep < a.frames_total and len(rows) >= a.frames_total and len(rows) % a.frames_total == 0:
+        per_frame = len(rows) // a.frames_total
+        rows = rows[-per_frame * a.frames_keep:]
+    return [v for _, v in rows]
+
 os.makedirs(out, exist_ok=True)
 import bench
 snap = bench.kernels_snapshot()
@@ -49,11 +63,14 @@ if os.path.exists(trace):
         if not k.startswith("pn_"):
             continue
         key = (k[:90], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
-        d[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        d[key].append((int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[key] = (r["Workgroup_Size_X"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
+    d = {k: steady(v) for k, v in d.items()}
     tot = sum(sum(v) for v in d.values())
     with open(os.path.join(out, f"{tag}_kernel_stats{suf}.csv"), "w") as f:
         f.write(f"# kernels_snapshot={snap}\n")
+        if a.frames_keep:
+            f.write(f"# steady state: the last {a.frames_keep} of {a.frames_total} frames of the profiled run\n")
         w = csv.writer(f)
         w.writerow(["kernel", "grid", "calls", "total_ms", "avg_us", "pct", "min_us", "max_us", "wg", "lds", "vgpr", "agpr", "sgpr", "scratch"])
         for key in sorted(d, key=lambda k: -sum(d[k])):
@@ -72,15 +89,17 @@ for sub in sorted(os.listdir(SRC)) if os.path.isdir(SRC) else []:
         if not k.startswith("pn_"):
             continue
         key = f"{k} grid={r['Grid_Size']}"
-        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 if agg:
     with open(os.path.join(out, f"{tag}_pmc_per_launch{suf}.csv"), "w") as f:
         f.write(f"# kernels_snapshot={snap}\n")
+        if a.frames_keep:
+            f.write(f"# steady state: the last {a.frames_keep} of {a.frames_total} frames of the profiled run\n")
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "launches", "avg", "min", "max"])
         for k in sorted(agg):
             for c in sorted(agg[k]):
-                v = agg[k][c]
+                v = steady(agg[k][c])
                 w.writerow([k, c, len(v), f"{sum(v)/len(v):.6g}", f"{min(v):.6g}", f"{max(v):.6g}"])
 bj = os.path.join(SRC, "stats_bench.json")
 if os.path.exists(bj):
