@@ -25,9 +25,6 @@
 #include <stdlib.h>
 
 #define BK 32
-#ifndef PN_GRU_WS_DEFAULT
-#define PN_GRU_WS_DEFAULT 0             // which batch GRU kernel a launch uses unless PERCEPNET_GRU_WS says otherwise
-#endif
 #define LDT 36            // padded LDS row stride (floats)
 // =============================== STRICT kernels ==================================================
 // W in the reference layout [K][ncols] (nnet_data.h); thread = (stream, neuron); the stream index is folded into
@@ -441,149 +438,10 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
 #endif
 }
 
-// ---- wave-specialised GRU step (round 5, verdict item 6): four MFMA waves + ONE loader wave per block ------------------------
-// Round 1's ablations of the kernel above (profiles/r01e_gemm_ablations.log): full 1.637 ms -> without its global loads 1.457 ->
-// MFMAs only 1.439.  The 7 global_load_dwordx4 and 11 ds_write a wave issues per K-tile between its MFMAs cost a ninth of the
-// kernel: VMEM and LDS-store issue from the wave that also feeds the matrix pipe.  Here two extra waves do ALL staging of their block
-// (per K-tile: 28 loads = the 16 KB activation tile + the three 4 KB gate weight tiles, 44 LDS stores, same LDS images and the
-// same double-buffer discipline: tile g + 1 is written during interval g, tile g + 2 requested right after) and the four MFMA
-// waves issue nothing but LDS operand reads, MFMAs and the block barrier.  384 threads; three waves per SIMD (two blocks per CU =
-// 12 waves) need <= 168 registers, which the MFMA waves reach because the two staging register sets are gone.
-// Same MFMAs in the same k order per accumulator: bit-identical to pn_gru_mfma_p_kernel (tests/test_gpu_parity.py).
-#define NN_WS_THREADS (NN_THREADS + 128)          // four MFMA waves + two loader waves (even / odd K-tiles)
-#ifndef PN_WS_WAVES
-#define PN_WS_WAVES 3
-#endif
-#ifndef PN_WS_ABL
-#define PN_WS_ABL 0                     // timing ablations: 1 = the loaders move nothing (results are garbage)
-#endif
-__global__ __launch_bounds__(NN_WS_THREADS, PN_WS_WAVES) void pn_gru_mfma_ws_kernel(
-    PnSegs X, const float *__restrict__ h_old, const float *__restrict__ Wp, const float *__restrict__ Up,
-    const float *__restrict__ b, int N, int KTx, int tps, int act, const float *__restrict__ tansig,
-    float *__restrict__ h_new, int n_rows, int n_mtiles) {
-  __shared__ NnShared S;
-  const int NTn = N >> 5;
-  int mt, nt;
-  if (!pn_tile_of_block(n_mtiles, NTn, mt, nt)) return;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m0 = mt * BM, KTh = N >> 5;
-  const int T1 = KTx, TT = KTx + KTh;
-  for (int i = tid; i < 201; i += NN_WS_THREADS) S.tansig[i] = tansig[i];
-  const float *Wz = Wp + (size_t)(0 * NTn + nt) * KTx * 1024, *Wr = Wp + (size_t)(1 * NTn + nt) * KTx * 1024,
-              *Wh = Wp + (size_t)(2 * NTn + nt) * KTx * 1024;
-  const float *Uz = Up + (size_t)(0 * NTn + nt) * KTh * 1024, *Ur = Up + (size_t)(1 * NTn + nt) * KTh * 1024,
-              *Uh = Up + (size_t)(2 * NTn + nt) * KTh * 1024;
-  PN_PANEL_LOCALS(X);
-  if (wave >= 4) {
-    // ================= loader waves: global -> registers -> LDS; wave 4 stages the even K-tiles, wave 5 the odd ones ===========
-    // (ONE loader has a single register set: a tile requested during interval g would have to be in LDS one interval later,
-    // less than a memory round trip under load — measured 2.42 ms; with two loaders a tile is requested two intervals ahead)
-    const int par = wave - 4;
-    // A tile (128 rows x 32 k): float4 number idx = lane + 64 it (it < 16) = row idx >> 3, k-chunk idx & 7; the three weight
-    // tiles: float4 number idx = lane + 64 j (j < 4) of each packed 1024-float tile (linear)
-    const unsigned aox = (unsigned)(((lane >> 3) * pld + 4 * (lane & 7)) * 4), aoh = (unsigned)(((lane >> 3) * N + 4 * (lane & 7)) * 4);
-    const unsigned bo = (unsigned)(lane * 16);
-    float4 ra[16], rb[3][4];
-#define WS_SEL(gg)                                                                                        \
-    int g_ = (gg); g_ = g_ < TT ? g_ : TT - 1;                                                             \
-    const bool p1_ = g_ < T1;                                                                              \
-    const int kx_ = p1_ ? g_ : 0, kh_ = p1_ ? 0 : g_ - T1;                                                 \
-    const int sg_ = kx_ / tps, k0_ = (kx_ - sg_ * tps) * BK;                                               \
-    const float *ap_ = (p1_ ? pn_seg_ptr(PN_PANEL_PASS, sg_) + (size_t)m0 * pld + k0_ : h_old + (size_t)m0 * N + kh_ * BK); \
-    const int ald_ = p1_ ? pld : N;                                                                        \
-    const size_t bo_ = (size_t)(p1_ ? kx_ : kh_) * 1024;                                                   \
-    const float *bz_ = (p1_ ? Wz : Uz) + bo_, *br_ = (p1_ ? Wr : Ur) + bo_, *bh_ = (p1_ ? Wh : Uh) + bo_
-#define WS_FETCH(gg) do { WS_SEL(gg);                                                                      \
-    _Pragma("unroll") for (int it = 0; it < 16; it++) ra[it] = pn_load_so(ap_ + (size_t)8 * it * ald_, p1_ ? aox : aoh); \
-    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                        \
-      rb[0][j] = pn_load_so(bz_ + 256 * j, bo); rb[1][j] = pn_load_so(br_ + 256 * j, bo); rb[2][j] = pn_load_so(bh_ + 256 * j, bo); } } while (0)
-#define WS_STASH(BUF) do {                                                                                 \
-    _Pragma("unroll") for (int it = 0; it < 16; it++) {                                                    \
-      const int row = (lane >> 3) + 8 * it, c = lane & 7;                                                  \
-      float *dst = &S.A[BUF][row][(c >> 1) * 8 + 2 * (c & 1)];                                             \
-      *reinterpret_cast<float2 *>(dst) = make_float2(ra[it].x, ra[it].z);                                  \
-      *reinterpret_cast<float2 *>(dst + 4) = make_float2(ra[it].y, ra[it].w); }                            \
-    _Pragma("unroll") for (int t = 0; t < 3; t++)                                                          \
-      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                      \
-        const int idx = lane + 64 * j;                                                                     \
-        *reinterpret_cast<float4 *>(&S.B[BUF][32 * t + (idx & 31)][4 * (idx >> 5)]) = rb[t][j]; } } while (0)
-    // tile t lives in LDS buffer t & 1 and is stashed during interval t - 1 by loader t & 1
-#if PN_WS_ABL & 1
-    __syncthreads();
-    for (int g = 0; g < TT; g++) __syncthreads();
-    return;
-#endif
-    if (par == 0) { WS_FETCH(0); WS_STASH(0); WS_FETCH(2); }
-    else WS_FETCH(1);
-    __syncthreads();
-#pragma unroll 1
-    for (int g = 0; g < TT; g += 2) {               // TT even (launcher)
-      if (par) { WS_STASH(1); WS_FETCH(g + 3); }     // interval g: tile g + 1 (odd) -> buffer 1, then request tile g + 3
-      __syncthreads();
-      if (!par) { WS_STASH(0); WS_FETCH(g + 4); }    // interval g + 1: tile g + 2 (even) -> buffer 0, then request tile g + 4
-      __syncthreads();
-    }
-#undef WS_SEL
-#undef WS_FETCH
-#undef WS_STASH
-    return;
-  }
-  // ================= MFMA waves =================
-  const int col = nt * 32 + (lane & 31);
-  floatx16 acc[4];
-  {
-    float bz = b[col]; bz += b[3 * N + col];    // nnet.cpp:135-141
-    float br = b[N + col]; br += b[4 * N + col];// 147-153
-    const float bt = b[5 * N + col];            // 164
-#pragma unroll
-    for (int i = 0; i < 16; i++) { acc[0][i] = bz; acc[1][i] = br; acc[2][i] = 0.f; acc[3][i] = bt; }
-  }
-  PnHalfOps<3> op0, op1;
-  // One interval: the operands of tile g come out of LDS under the MFMAs of half 1 of tile g - 1 and of half 0 of tile g
-#define WS_INTERVAL(BUF, PI2, CI2, HAVE_PREV) do {                                                         \
-    PN_SB();                                                                                               \
-    pn_lds_read_q<3, 0, 0>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
-    if (HAVE_PREV) PN_G3(op1, 0, x, 0, 1, PI2);                                                            \
-    pn_lds_read_q<3, 0, 1>(op0, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
-    if (HAVE_PREV) { PN_G3(op1, 0, y, 0, 1, PI2); PN_G3(op1, 0, z, 0, 1, PI2); PN_G3(op1, 0, w, 0, 1, PI2);  \
-                     PN_G3(op1, 1, x, 0, 1, PI2); PN_G3(op1, 1, y, 0, 1, PI2); PN_G3(op1, 1, z, 0, 1, PI2); PN_G3(op1, 1, w, 0, 1, PI2); } \
-    PN_G3(op0, 0, x, 0, 1, CI2);                                                                           \
-    pn_lds_read_q<3, 1, 0>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
-    PN_G3(op0, 0, y, 0, 1, CI2);                                                                           \
-    pn_lds_read_q<3, 1, 1>(op1, S.A[BUF], S.B[BUF], wave, lane); PN_SB();                                  \
-    PN_G3(op0, 0, z, 0, 1, CI2); PN_G3(op0, 0, w, 0, 1, CI2);                                              \
-    PN_G3(op0, 1, x, 0, 1, CI2); PN_G3(op0, 1, y, 0, 1, CI2); PN_G3(op0, 1, z, 0, 1, CI2); PN_G3(op0, 1, w, 0, 1, CI2); \
-    __syncthreads();                                                                                       \
-  } while (0)
-  __syncthreads();
-  WS_INTERVAL(0, 2, 2, false);
-#pragma unroll 1
-  for (int g = 1; g + 1 < T1; g += 2) {
-    WS_INTERVAL(1, 2, 2, true);
-    WS_INTERVAL(0, 2, 2, true);
-  }
-  WS_INTERVAL(1, 2, 2, true);                      // last x tile (T1 even)
-  WS_INTERVAL(0, 2, 3, true);                      // first h tile; its first half still runs the x tile's MFMAs
-#pragma unroll 1
-  for (int g = T1 + 1; g + 1 < TT; g += 2) {
-    WS_INTERVAL(1, 3, 3, true);
-    WS_INTERVAL(0, 3, 3, true);
-  }
-  WS_INTERVAL(1, 3, 3, true);
-  PN_G3(op1, 0, x, 0, 1, 3); PN_G3(op1, 0, y, 0, 1, 3); PN_G3(op1, 0, z, 0, 1, 3); PN_G3(op1, 0, w, 0, 1, 3);
-  PN_G3(op1, 1, x, 0, 1, 3); PN_G3(op1, 1, y, 0, 1, 3); PN_G3(op1, 1, z, 0, 1, 3); PN_G3(op1, 1, w, 0, 1, 3);
-#undef WS_INTERVAL
-  // gates, candidate, blend (nnet.cpp:144,156,161-179)
-  {
-    const float bh = b[2 * N + col];
-    float ho[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-      ho[i] = h_old[(size_t)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * N + col];
-    pn_gru_epilogue(acc, ho, bh, act, S.tansig, h_new, nullptr, N, col, m0 + 32 * wave + 4 * (lane >> 5), n_rows);
-  }
-}
-
+// (Round 5, verdict item 6: a wave-specialised form of the kernel above — four MFMA waves that issue only LDS operand reads, MFMAs and
+// the barrier, one or two loader waves doing all the staging — was built, is bit-identical and SLOWER (2.2-2.4 ms); its ablation with
+// loaders that move nothing takes 1.548 ms: with no staging at all this tile shape is 1.2 % faster than the kernel above.  The record is
+// profiles/r05_gru_wave_specialised.log; the kernel is in the history, one commit before this note.)
 // Dense / conv-as-dense with the same half-tile pipeline (KT even, >= 2).
 #define PN_DN(o, QQ, c) do {                                                                               \
     _Pragma("unroll") for (int t_ = 0; t_ < NT; t_++)                                                      \
@@ -746,13 +604,7 @@ int pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_ol
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int n_mtiles = (n_rows + BM - 1) / BM, NTn = N / 32;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
-  // PERCEPNET_GRU_WS=0|1: the wave-specialised kernel (four MFMA waves + a loader wave per block); it consumes K-tiles in pairs
-  static const int ws = getenv("PERCEPNET_GRU_WS") ? atoi(getenv("PERCEPNET_GRU_WS")) : PN_GRU_WS_DEFAULT;
-  if (ws && (KTx & 1) == 0 && ((N / 32) & 1) == 0)
-    hipLaunchKernelGGL(pn_gru_mfma_ws_kernel, dim3(grid), dim3(NN_WS_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
-                       tansig, h_new, n_rows, n_mtiles);
-  else
-    hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
+  hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
                        tansig, h_new, n_rows, n_mtiles);
   return 0;
 }
