@@ -28,7 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 
 # per-source extra flags.  pn_nn_x3.hip: no SLP vectorisation — packed f32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32)
-# issued beside a wave that keeps the SIMD's matrix pipe busy are 4x slower than beside an idle one (DESIGN.md 4.2f,
+# issued beside a wave that keeps the SIMD's matrix pipe busy are 4x slower than beside an idle one (NOTES_history.md, round-4 DESIGN 4.2f;
 # tools/probes/mfma_valu_pair_probe.hip), and the gating epilogues of these kernels run exactly there
 # -pragma-unroll-threshold: the paired-phase GRU kernel's epilogue phase is ONE fully unrolled loop over its 32 / 36 barrier steps
 # (every step then has compile-time register sets, ring slots and tile numbers); the default limit of `#pragma unroll` (16 K
@@ -43,13 +43,13 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-# The kernels were validated with this toolchain (the MFMA wait-state rule is met by the compiler's own
+# The kernels were validated with this toolchain (NOTES_history.md: the MFMA wait-state rule is met by the compiler's own
 # padding, with zero margin); a different hipcc is allowed but announced, and the create-time self-tests of the network
 # and DSP kernels (pn_ctx_create) are what guard the results.
 EXPECTED_HIP = "7.2"
 
 # Register hygiene gate for the PRODUCTION DSP kernels: the single-launch front end of rounds 1-2 ran at 256 VGPRs + 219
-# AGPR spill copies, the regime in which a register-allocation-dependent corruption once appeared.  The
+# AGPR spill copies, the regime in which a register-allocation-dependent corruption once appeared (NOTES_history.md).  The
 # phase-split kernels and the back end must stay free of AGPR spill copies and (almost) free of scratch; the build fails
 # otherwise.  kernel-name prefix -> (max AGPRs, max scratch bytes per lane)
 RESOURCE_LIMITS = {"pn_fe_spec_in_kernel": (0, 0), "pn_fe_spec_out_kernel": (0, 40), "pn_fe_pitch_kernel": (0, 48),

@@ -183,7 +183,7 @@ def test_configs2_65536_streams_1000_frames_256_sampled_vs_oracle(model, oracle)
 
 def test_fp16_variant_1000_frames_tolerance_holds(model, oracle):
     """configs[4] (fp16 GEMM operands, fp32 accumulate/state/DSP) over the same 10 s horizon: the re-stated tolerance
-    (PCM <= 6 LSB stated, 4 measured; g/r <= 1e-3, DESIGN.md 4.2b) must hold for all 1000 frames — the recurrent state sees rounded
+    (PCM <= 6 LSB stated, 4 measured; g/r <= 1e-3, DESIGN.md §4.4) must hold for all 1000 frames — the recurrent state sees rounded
     operands every step, so this is where a slow drift would show — and the features, which never touch the
     network, stay bit-equal."""
     import torch

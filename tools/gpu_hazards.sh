@@ -1,5 +1,5 @@
 #!/bin/bash
-# DESIGN.md §4.3/§4.4 evidence: (1) how many wait states gfx950 really needs after v_mfma_f32_32x32x2_f32, (2) the loop-exit
+# NOTES_history.md (round-4 DESIGN §4.3/§4.4) evidence: (1) how many wait states gfx950 really needs after v_mfma_f32_32x32x2_f32, (2) the loop-exit
 # reproducer as hipcc compiles it, (3) the parity / placement tests on builds WITHOUT the manual MFMA drain and WITHOUT the
 # DSP loop back-edge padding.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
