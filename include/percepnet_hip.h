@@ -119,6 +119,10 @@ int pn_process_i16(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr
    and ~52 KB of ring entries shifted per skipped stream-tick), nothing is added to an all-active call. */
 int pn_process_f32_active(pn_ctx *ctx, const float *d_in, float *d_out, float *d_gr, const int32_t *ids, int n);
 int pn_process_i16_active(pn_ctx *ctx, const int16_t *d_in, int16_t *d_out, float *d_gr, const int32_t *ids, int n);
+/* The same on the pipelined host path (see pn_submit_host_* below): rows of h_in of skipped streams are ignored; their rows of
+   h_out / h_gr are UNSPECIFIED for that frame (the caller knows which streams it listed).  A refused id list consumes no slot. */
+int pn_submit_host_f32_active(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr, const int32_t *ids, int n);
+int pn_submit_host_i16_active(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr, const int32_t *ids, int n);
 /* Optional output stage: the reference's envelope post-filter
    (post_filtering, denoise.cpp:216-250), which it only runs on train()'s TEST synthesis (743),
    applied to the gains inside the back-end kernel between the g/r tap and pitch_filter — the same

@@ -62,8 +62,9 @@ def load_library():
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_process_i16_multi.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_int]
     if hasattr(L, "pn_process_i16_active"):                 # (a round-4 library loaded through PERCEPNET_LIB for A/B timing has none of these)
-        for name in ("pn_process_f32_active", "pn_process_i16_active"):
-            getattr(L, name).argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]
+        for name in ("pn_process_f32_active", "pn_process_i16_active", "pn_submit_host_f32_active", "pn_submit_host_i16_active"):
+            if hasattr(L, name):
+                getattr(L, name).argtypes = [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]
         L.pn_debug_check_launch.argtypes = [ctypes.c_int] * 4
         L.pn_ctx_debug_inject_launch_failure.argtypes = [_vp, ctypes.c_int]
     for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
@@ -206,6 +207,10 @@ class Context:
     # pipelined host-buffer entry points (raw host pointers; the buffers should be pinned and must outlive delivery)
     def submit_host_i16(self, h_in, h_out, h_gr=None):
         self._chk(self.L.pn_submit_host_i16(self.h, h_in, h_out, h_gr))
+
+    def submit_host_i16_active(self, h_in, h_out, h_gr, ids):
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).ravel())
+        self._chk(self.L.pn_submit_host_i16_active(self.h, h_in, h_out, h_gr, a.ctypes.data, int(a.size)))
 
     def host_wait(self):
         self._chk(self.L.pn_host_wait(self.h))

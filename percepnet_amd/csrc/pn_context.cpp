@@ -562,8 +562,8 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
   return H;
 }
 
-// Returns 0, or -1 when a launcher refused its geometry (pn_set_error names it): nothing after the refused layer is
-// launched and the caller fails the frame.
+// Returns 0, or -1 when a launcher refused its geometry (pn_set_error names it): the refused layer is not launched (later
+// layers of the frame may be — their results are never reported) and the caller fails the frame.
 static int launch_rnn(pn_ctx *c) {
   const size_t B = c->B, Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
   // x3: the layers that run on the fp16 matrix cores from operand shadows — split precision (hi + lo planes) or fp16 operands (hi only)
@@ -847,8 +847,9 @@ extern "C" int pn_process_i16_multi(pn_ctx *c, const int16_t *d_in, int16_t *d_o
 // ids[0..n): the streams that receive a frame in this call (distinct, any order).  Every other stream keeps ALL of its
 // state — as if its rnnoise_process_frame had not been called (denoise.cpp:508-547) — and its rows of d_out / d_gr are
 // left as they were; its row of d_in is ignored.  n == n_streams is exactly pn_process_*.
-static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16, const int32_t *ids, int n) {
-  if (!c || !d_in || !d_out || n < 0 || (n > 0 && !ids)) { pn_set_error("bad argument"); return -1; }
+// the active list must name distinct streams of this context; leaves c->act.mark[s] = 1 for the listed ones
+static int active_check(pn_ctx *c, const int32_t *ids, int n) {
+  if (!c || n < 0 || (n > 0 && !ids)) { pn_set_error("bad argument"); return -1; }
   const int B = c->B;
   if (n > B) { pn_set_error("%d active streams in a context of %d", n, B); return -1; }
   pn_ctx::Active &A = c->act;
@@ -858,6 +859,13 @@ static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr,
     if (A.mark[ids[i]]) { pn_set_error("stream id %d listed twice", ids[i]); return -1; }
     A.mark[ids[i]] = 1;
   }
+  return 0;
+}
+static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16, const int32_t *ids, int n) {
+  if (!c || !d_in || !d_out) { pn_set_error("NULL argument"); return -1; }
+  if (active_check(c, ids, n)) return -1;
+  const int B = c->B;
+  pn_ctx::Active &A = c->act;
   if (n == B) return process_dev(c, d_in, d_out, d_gr, is_i16);
   A.inactive.clear();
   for (int s = 0; s < B; s++) if (!A.mark[s]) A.inactive.push_back(s);
@@ -958,8 +966,12 @@ static int pipe_drain(pn_ctx *c) {
   return 0;
 }
 
-static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16) {
+static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr, int is_i16, const int32_t *ids, int n);
+static int active_check(pn_ctx *c, const int32_t *ids, int n);
+// ids != NULL or n >= 0 with active = true: only the listed streams advance (pn_submit_host_*_active)
+static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, int is_i16, bool active = false, const int32_t *ids = NULL, int n = 0) {
   if (!c || !h_in || !h_out) { pn_set_error("NULL argument"); return -1; }
+  if (active && active_check(c, ids, n)) return -1;          // refused before the frame takes a pipeline slot
   PN_ON_DEVICE(c);
   if (pipe_init(c)) return -1;
   pn_ctx::Pipe &P = c->pipe;
@@ -969,7 +981,8 @@ static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, in
   PN_HIP_CHECK(hipMemcpyAsync(P.in[k], h_in, nbytes, hipMemcpyHostToDevice, P.h2d));
   PN_HIP_CHECK(hipEventRecord(P.in_ready[k], P.h2d));
   PN_HIP_CHECK(hipStreamWaitEvent(c->stream, P.in_ready[k], 0));
-  if (process_dev(c, P.in[k], P.out[k], h_gr ? P.gr[k] : NULL, is_i16)) return -1;
+  if (active ? process_active(c, P.in[k], P.out[k], h_gr ? P.gr[k] : NULL, is_i16, ids, n)
+             : process_dev(c, P.in[k], P.out[k], h_gr ? P.gr[k] : NULL, is_i16)) return -1;
   PN_HIP_CHECK(hipEventRecord(P.done[k], c->stream));
   PN_HIP_CHECK(hipStreamWaitEvent(P.d2h, P.done[k], 0));
   PN_HIP_CHECK(hipMemcpyAsync(h_out, P.out[k], nbytes, hipMemcpyDeviceToHost, P.d2h));
@@ -980,6 +993,10 @@ static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, in
 }
 extern "C" int pn_submit_host_f32(pn_ctx *c, const float *h_in, float *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 0); }
 extern "C" int pn_submit_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 1); }
+// The pipelined path with a per-call active set: rows of h_in of skipped streams are ignored; their rows of h_out / h_gr are
+// UNSPECIFIED (the device staging rows are restored to what they held two frames earlier and copied out with the rest).
+extern "C" int pn_submit_host_f32_active(pn_ctx *c, const float *h_in, float *h_out, float *h_gr, const int32_t *ids, int n) { return submit_host(c, h_in, h_out, h_gr, 0, true, ids, n); }
+extern "C" int pn_submit_host_i16_active(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr, const int32_t *ids, int n) { return submit_host(c, h_in, h_out, h_gr, 1, true, ids, n); }
 extern "C" int pn_host_wait(pn_ctx *c) {
   if (!c) { pn_set_error("NULL argument"); return -1; }
   PN_ON_DEVICE(c);

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(FS_THREADS, PN_FS_WAVES_OUT) void pn_fe_spec_out_ke
     const float Ey = l < PN_NB ? eyring[((size_t)slot_w * n_streams + s) * 36 + l] : 0.f;   // Ey of this frame
     // comb filter (denoise.cpp:416-422): lane l < 60 filters samples 4l + 240k .. +3, k = 0..3; one unaligned dwordx4
     // load per tap (the ring carries an 8-sample mirror).  Two k at a time: 14 loads in flight.
-    // Measured in round 5 (profiles/r05_fe_steady_state.log, r05_fetch_size_calibration.log): in steady state the windows
+    // Measured in round 5 (profiles/r05_fe_steady_state.log, r05_front_end_variants.log, r05_fetch_size_calibration.log): in steady state the windows
     // two taps share ARE served once — 22.5 KB of traffic per stream against 21.8 KB of algorithmic bytes (mean period 446);
     // a tap-major order with 8 .. 28 loads in flight moved 23.4 KB in the same time, a cross-stream pipeline at two waves
     // per SIMD (all 28 windows of the next stream requested under the current stream's transform) was 35 % slower.

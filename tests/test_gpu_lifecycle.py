@@ -256,3 +256,44 @@ def test_a_refused_launch_fails_the_frame(model, mode):
         assert np.array_equal(ctx.process_i16(pcm[:, t * 480:(t + 1) * 480])[0], good.process_i16(pcm[:, t * 480:(t + 1) * 480])[0])
     ctx.close(); good.close()
 
+
+def test_active_set_on_the_pipelined_host_path(model):
+    """pn_submit_host_i16_active = pn_process_i16_active behind the pipelined copy-in / compute / copy-out path: the rows of
+    the streams that take part equal the device-pointer path's bit for bit, also after a stream has skipped ticks; a refused
+    id list consumes no pipeline slot."""
+    import ctypes
+    import torch
+    B, T = 64, 14
+    skips = {5: {4, 5}, 63: {9}}
+    pcm = synth.synth_batch(B, T)
+    dev = torch.device("cuda:0")
+    ref = api.Context(model, B, nn_mode=api.NN_STRICT)
+    d_out = torch.zeros((B, 480), dtype=torch.int16, device=dev)
+    want = []
+    for t in range(T):
+        act = [s for s in range(B) if not (s in skips and t in skips[s])]
+        d_in = torch.from_numpy(np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])).to(dev)
+        torch.cuda.synchronize()
+        ref.process_i16_active_dev(d_in.data_ptr(), d_out.data_ptr(), None, act)
+        ref.synchronize()
+        want.append((act, d_out.cpu().numpy().copy()))
+    ref.close()
+    ctx = api.Context(model, B, nn_mode=api.NN_STRICT)
+    L = ctx.L
+    n = B * 480
+    bufs = [(L.pn_host_alloc(n * 2), L.pn_host_alloc(n * 2)) for _ in range(T)]
+    with pytest.raises(api.PercepNetError):
+        ctx.submit_host_i16_active(bufs[0][0], bufs[0][1], None, [0, 0])
+    for t in range(T):
+        fr = np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])
+        ctypes.memmove(bufs[t][0], fr.ctypes.data, n * 2)
+        ctx.submit_host_i16_active(bufs[t][0], bufs[t][1], None, want[t][0])
+    ctx.host_wait()
+    assert L.pn_host_frames_delivered(ctx.h) == T
+    for t in range(T):
+        got = np.ctypeslib.as_array(ctypes.cast(bufs[t][1], ctypes.POINTER(ctypes.c_int16)), shape=(B, 480))
+        act = want[t][0]
+        assert np.array_equal(got[act], want[t][1][act]), t
+    for a, b in bufs:
+        L.pn_host_free(a); L.pn_host_free(b)
+    ctx.close()
