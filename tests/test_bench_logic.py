@@ -1,0 +1,106 @@
+"""CPU-only checks of the MEASUREMENT code (bench.py, tools/summarize_prof.py): the numbers in the bench line must follow from
+the run — these are the pure functions behind them, exercised without a GPU."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_spec_out_algorithmic_bytes_follow_from_the_runs_periods():
+    """fe_spec_out reads the comb window [2400 - 3T, 3360 + 3T) = 960 + 6T samples of each stream (reference denoise.cpp:416-422):
+    its algorithmic bytes are the sum over the run's own periods + the fixed rows, the T = 768 figure is kept beside them."""
+    B = 1000
+    T = np.full(B, 400, dtype=np.int32); T[:100] = 768; T[100:200] = 60
+    kt = {"fe_spec_out": (0.5, 2), "fe_pitch": (1.0, 2)}
+    r = bench.dsp_roofline(kt, B, tag="_no_such_profile", periods=T)
+    so = r["fe_spec_out"]
+    want = int(((960 + 6 * T.astype(np.int64)) * 4).sum()) + B * bench.SPEC_OUT_FIXED
+    assert so["algorithmic_bytes"] == want and so["algorithmic_bytes_worst_case"] == B * (22272 + bench.SPEC_OUT_FIXED)
+    assert abs(so["pitch_period_mean"] - float(T.mean())) < 0.06 and so["ms"] == 0.25
+    assert abs(so["frac"] - want / 0.25e-3 / 1e12 / 8.0) < 1e-4
+    assert so["traffic"] is None                                   # no profile of these kernels: refused, not invented
+    worst = bench.dsp_roofline(kt, B, tag="_no_such_profile", periods=None)["fe_spec_out"]
+    assert worst["algorithmic_bytes"] == worst["algorithmic_bytes_worst_case"] and "worst case" in worst["algorithmic_bytes_source"]
+    assert r["dsp_total"]["algorithmic_bytes"] == want + B * bench.DSP_KERNELS["fe_pitch"][1]
+
+
+def test_capacity_search_bisects_and_reports_the_next_size(monkeypatch):
+    """realtime_capacity: the largest batch of the 512-stream grid whose runs ALL pass, the pass rate of the next size up, a
+    fallback to smaller batches when 65 536 itself fails — with a fake paced run (a batch passes iff it is <= a limit; one size
+    is flaky)."""
+    class FakeCtx:
+        def __init__(self, *a, **k): pass
+        def close(self): pass
+
+    class FakeApi:
+        Context = FakeCtx
+        NN_MFMA = 0
+
+    calls = []
+
+    def fake_paced(limit, flaky=None):
+        def f(api, synth, model, dev, b, mode, seconds, ctx=None):
+            calls.append(b)
+            ok = b <= limit and not (b == flaky and calls.count(b) == 2)
+            return {"streams": b, "deadline_misses": 0 if ok else 7, "delivery_latency_ms": {"p99": 12.0 if ok else 80.0}, "met_contract": ok}
+        return f
+
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(67700))
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
+    assert r["realtime_streams_p99"] == 67584 and r["next_size"] == {"streams": 68096, "runs": 3, "passed": 0}
+    assert r["sizes"]["67584"]["passed"] == 3 and set(r["sizes"]) == {"65536", "67584", "68096", "68608"}
+    calls.clear()
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9))
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    assert r["realtime_streams_p99"] == 69632 and r["next_size"] is None
+    calls.clear()
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9, flaky=67584))          # one run of three fails at 67 584
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
+    assert r["realtime_streams_p99"] == 67072 and r["next_size"] == {"streams": 67584, "runs": 3, "passed": 2}
+    calls.clear()
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(60000))
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 1, lambda m: None)
+    assert r["realtime_streams_p99"] == 57344 and r["next_size"]["streams"] == 65536
+
+
+def test_profile_summaries_keep_only_the_steady_state_frames(tmp_path):
+    """tools/summarize_prof.py --frames-total W+K --frames-keep K: of every (kernel, grid) only the launches of the last K frames
+    count — the first frames of a run from the zero state filter at the degenerate period and move more bytes."""
+    src = tmp_path / "prof"; (src / "pmc_fetch").mkdir(parents=True); (src / "stats").mkdir()
+    with open(src / "pmc_fetch" / "bench_counter_collection.csv", "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+        d = 0
+        for frame in range(10):                                   # 10 frames: one spec_out launch and four GRU launches each
+            d += 1; w.writerow([d, "pn_fe_spec_out_kernel(args)", 196608, "FETCH_SIZE", 900.0 if frame < 6 else 600.0])
+            for _ in range(4):
+                d += 1; w.writerow([d, "pn_gru_mfma_p_kernel(args)", 2097152, "FETCH_SIZE", 100.0 + frame])
+        w.writerow([d + 1, "pn_fe_spec_out_kernel(args)", 256, "FETCH_SIZE", 1.0])      # a self-test launch on another grid: its own key
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), "t", "--src", str(src), "--out", str(out),
+                        "--frames-total", "10", "--frames-keep", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(out / "t_pmc_per_launch.csv").read().splitlines()
+    assert lines[0].startswith("# kernels_snapshot=") and "last 4 of 10 frames" in lines[1]
+    rows = {(x["kernel"], x["counter"]): x for x in csv.DictReader(lines[2:])}
+    so = rows[("pn_fe_spec_out_kernel grid=196608", "FETCH_SIZE")]
+    assert so["launches"] == "4" and float(so["avg"]) == 600.0
+    gru = rows[("pn_gru_mfma_p_kernel grid=2097152", "FETCH_SIZE")]
+    assert gru["launches"] == "16" and abs(float(gru["avg"]) - 107.5) < 1e-9
+    assert rows[("pn_fe_spec_out_kernel grid=256", "FETCH_SIZE")]["launches"] == "1"
+
+
+def test_design_table_is_generated_from_the_committed_bench_lines():
+    """DESIGN.md's status table is what tools/design_table.py makes of profiles/r05_bench*.json (numbers cannot go stale)."""
+    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    a, b = s.index("<!-- BEGIN GENERATED"), s.index("<!-- END GENERATED -->")
+    block = s[a:b]
+    d = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench.json")) if l.startswith("{")][-1])
+    assert f"| {d['ms_per_step']} |" in block and f"{d['value']:.0f}" in block
+    assert str(d["realtime_streams_p99"]) in block and d["roofline"]["kernels_snapshot"] in block
