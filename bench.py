@@ -405,10 +405,11 @@ def percentiles(ms):
             "mean": round(float(a.mean()), 4), "frames": int(a.size)}
 
 
+STALL_AT_FRAME, STALL_MS, RECOVERY_FRAMES = 100, 50.0, 300   # the disturbed paced run: a 50 ms host stall, back on the clock within 3 s
 DELIVERY_DEADLINE_MS = 20.0          # two frame periods = the depth of the pipelined host path (two frames in flight)
 
 
-def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=None):
+def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=None, sample_clock=True, stall=None):
     """The real-time contract itself (reference main.cpp:30-39: one 480-sample frame per stream every 10 ms), not an
     extrapolation from a mean: a frame of B streams arrives on the HOST every 10.000 ms for `seconds` and goes through the
     pipelined host entry points (pn_submit_host_i16: pinned buffers, copy-in / compute / copy-out on three streams, two
@@ -419,7 +420,11 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
         every frame whose output copy has landed (resolution ~0.2 ms): `delivery_latency_ms` p50 / p99 / max.
     `met_contract`: no back-pressure miss, delivery p99 within DELIVERY_DEADLINE_MS (the pipeline is two frames deep: a
     frame must be out before the frame after next arrives), and the run did not end behind its clock.
-    ctx: reuse an open context of B streams (reset first); otherwise one is created and closed here."""
+    ctx: reuse an open context of B streams (reset first); otherwise one is created and closed here.
+    stall = (frame, ms): a host hiccup is INJECTED — the submit of that frame is held back by `ms` — and the run then reports
+    whether the pipeline caught up with its clock again (`recovery`): a size whose back-to-back rate is below the arrival rate
+    passes an undisturbed run and never recovers from a disturbed one.  `host_pipeline_back_to_back_ms`: 100 frames submitted
+    without pacing, the rate the pipeline sustains when it is behind."""
     import ctypes
     import numpy as np
     own = ctx is None
@@ -448,6 +453,11 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
             if L.pn_process_host_i16(ctx.h, bufs[k][0], bufs[k][1], None):
                 raise RuntimeError("pn_process_host_i16 failed")
             ser.append(time.perf_counter() - t_s)
+        t_s = time.perf_counter()
+        for k in range(100):                                 # back to back: what the pipeline sustains once it is behind its clock
+            ctx.submit_host_i16(*bufs[k % 3])
+        ctx.host_wait()
+        b2b_ms = (time.perf_counter() - t_s) * 10.0
         base = L.pn_host_frames_delivered(ctx.h)             # frames delivered before the paced loop starts
         if base < 0:
             raise RuntimeError("pn_host_frames_delivered failed")
@@ -462,7 +472,7 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
             while nd < min(d, N):
                 deliv[nd] = now; nd += 1
 
-        with ClockSampler() as clk:
+        with ClockSampler(period=0.5 if sample_clock else 1e9) as clk:
             t0 = time.perf_counter() + 0.002
             for t in range(N):
                 a_t = t0 + period * t
@@ -473,6 +483,9 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
                         break
                     if a_t - now > 0.0004:
                         time.sleep(0.0002)
+                if stall is not None and t == stall[0]:
+                    time.sleep(stall[1] * 1e-3)                # the injected host hiccup
+                    now = time.perf_counter()
                 arrive[t] = a_t; start[t] = now
                 ctx.submit_host_i16(*bufs[t % 3])
                 ret[t] = time.perf_counter()
@@ -492,11 +505,22 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
                "frames_delivered_late": int((lat > DELIVERY_DEADLINE_MS).sum()),
                "submit_call_ms": percentiles((ret - start) * 1e3), "submit_backlog_ms_max": round(float(backlog.max()) * 1e3, 4),
                "finished_behind_schedule_ms": round((t_end - (t0 + period * N)) * 1e3, 4),
-               "serial_host_call_ms": round(1e3 * min(ser), 3),
+               "serial_host_call_ms": round(1e3 * min(ser), 3), "host_pipeline_back_to_back_ms": round(b2b_ms, 4),
+               "copy_streams": ctx.pipe_streams(),
                "path": "pn_submit_host_i16 (pinned host buffers, PCIe both ways inside the loop); delivery stamped by polling "
                        "pn_host_frames_delivered between arrivals (~0.2 ms resolution)"}
         out["met_contract"] = bool(out["deadline_misses"] == 0 and lat.size == N and out["delivery_latency_ms"]["p99"] <= DELIVERY_DEADLINE_MS
                                    and out["finished_behind_schedule_ms"] < 10.0)
+        if stall is not None:
+            # recovery: the first frame after the hiccup that is submitted on its arrival again (backlog < 0.5 ms), with no
+            # back-pressure miss from there to the end of the run
+            after = np.nonzero(backlog[stall[0] + 1:] < 0.0005)[0]
+            rec = int(after[0]) + 1 if after.size else None
+            clean = bool(rec is not None and rec <= RECOVERY_FRAMES and (late[stall[0] + rec:] > 0).sum() == 0
+                         and out["finished_behind_schedule_ms"] < 10.0)
+            out["recovery"] = {"stall_at_frame": int(stall[0]), "stall_ms": float(stall[1]), "frames_to_recover": rec,
+                               "recovery_limit_frames": RECOVERY_FRAMES, "recovered": clean}
+            out["met_contract"] = clean
         out.update(clk.summary())
         return out
     finally:
@@ -510,10 +534,13 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
             ctx.close()
 
 
-def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log):
+def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log, soak_seconds=0.0):
     """Deadline-PROVEN capacity (round-4 verdict item 4): the largest batch in 65 536 .. 69 632 (512-stream grid) that meets
-    the paced contract in EVERY one of `runs` runs, found by bisection (a larger batch is never easier), plus the pass rate
-    of the next size up.  Falls back to smaller batches when 65 536 itself fails."""
+    the paced contract in EVERY one of `runs` undisturbed runs AND catches up with its clock after an injected host stall
+    (STALL_MS at frame STALL_AT_FRAME, back within RECOVERY_FRAMES: a pipeline whose back-to-back rate is not above the arrival
+    rate passes undisturbed runs and fails the first hiccup of a long one — profiles/r05_realtime_robustness.log), found by
+    bisection (a larger batch is never easier); then confirmed by one run of `soak_seconds` (stepping down the grid while that
+    fails).  Falls back to smaller batches when 65 536 itself fails."""
     grid = [65536 + 512 * k for k in range(9)]
     tried = {}
 
@@ -525,16 +552,19 @@ def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log)
             tried[b] = [{"streams": b, "error": f"{type(e).__name__}: {e}"}]
             return False
         try:
-            for _ in range(runs):
+            for i in range(runs + 1):
+                kw = {"stall": (STALL_AT_FRAME, STALL_MS)} if i == runs else {}
                 try:
-                    res.append(paced_realtime(api, synth, model, dev_index, b, nn_mode, seconds, ctx=ctx))
+                    res.append(paced_realtime(api, synth, model, dev_index, b, nn_mode, seconds, ctx=ctx, **kw))
                 except Exception as e:        # noqa: BLE001
                     res.append({"streams": b, "error": f"{type(e).__name__}: {e}"})
         finally:
             ctx.close()
         tried[b] = res
         ok = all(r.get("met_contract") for r in res)
-        log(f"[bench] paced real-time {b} streams: {sum(bool(r.get('met_contract')) for r in res)}/{len(res)} runs met the contract")
+        rec = res[-1].get("recovery") or {}
+        log(f"[bench] paced real-time {b} streams: {sum(bool(r.get('met_contract')) for r in res[:runs])}/{runs} undisturbed runs met the "
+            f"contract; after a {STALL_MS:.0f} ms stall back on the clock in {rec.get('frames_to_recover')} frames (limit {RECOVERY_FRAMES})")
         return ok
 
     best = None
@@ -554,17 +584,47 @@ def realtime_capacity(api, synth, model, dev_index, nn_mode, seconds, runs, log)
             if probe(b):
                 best = b
                 break
-    summary = {b: {"runs": len(r), "passed": sum(bool(x.get("met_contract")) for x in r),
-                   "deadline_misses": [x.get("deadline_misses") for x in r],
-                   "delivery_latency_ms_p99": [(x.get("delivery_latency_ms") or {}).get("p99") for x in r]} for b, r in sorted(tried.items())}
+    soaks = []
+    while best is not None and soak_seconds > 0:
+        try:
+            r = paced_realtime(api, synth, model, dev_index, best, nn_mode, soak_seconds)
+        except Exception as e:                # noqa: BLE001
+            r = {"streams": best, "error": f"{type(e).__name__}: {e}"}
+        soaks.append(r)
+        log(f"[bench] paced real-time {best} streams, {soak_seconds:.0f} s confirmation run: {'met' if r.get('met_contract') else 'MISSED'} the contract")
+        if r.get("met_contract"):
+            break
+        nxt, cand, best = best, best - 512, None          # the next smaller grid size that passes its own probe
+        while cand >= grid[0] and len(soaks) < 4:
+            if all(x.get("met_contract") for x in tried[cand]) if cand in tried else probe(cand):
+                best = cand
+                break
+            cand -= 512
+
+    def size_summary(r):
+        und = [x for x in r if not x.get("recovery")]
+        dis = [x for x in r if x.get("recovery")]
+        return {"runs": len(und), "passed": sum(bool(x.get("met_contract")) for x in und),
+                "deadline_misses": [x.get("deadline_misses") for x in und],
+                "delivery_latency_ms_p99": [(x.get("delivery_latency_ms") or {}).get("p99") for x in und],
+                "host_pipeline_back_to_back_ms": [x.get("host_pipeline_back_to_back_ms") for x in r],
+                "stall_recovery": [x["recovery"] for x in dis]}
+
+    summary = {b: size_summary(r) for b, r in sorted(tried.items())}
+    und_ok = [b for b, r in tried.items() if all(x.get("met_contract") for x in r if not x.get("recovery"))]
     return {"realtime_streams_p99": best,
-            "next_size": None if nxt is None else {"streams": nxt, "runs": summary[nxt]["runs"], "passed": summary[nxt]["passed"]},
+            "largest_size_passing_undisturbed_runs": max(und_ok) if und_ok else None,
+            "next_size": None if nxt is None or nxt not in summary else {"streams": nxt, "runs": summary[nxt]["runs"], "passed": summary[nxt]["passed"],
+                                                   "recovered": [x.get("recovered") for x in summary[nxt]["stall_recovery"]]},
             "sizes": {str(b): v for b, v in summary.items()},
             "paced_runs": [r for b in sorted(tried) for r in tried[b]],
+            "confirmation_runs": soaks, "confirmation_seconds": soak_seconds,
             "runs_per_size": runs, "seconds_per_run": seconds, "grid": "65536 + 512 k, k = 0..8",
             "contract": "one 480-sample frame per stream every 10 ms (reference src/main.cpp:30-39): frames arrive on the host on a 10.000 ms "
                         f"clock, pipelined host path with PCIe in the loop; a run passes with zero back-pressure misses, delivery p99 <= "
-                        f"{DELIVERY_DEADLINE_MS} ms after arrival and no schedule slip; a size passes when ALL its runs pass"}
+                        f"{DELIVERY_DEADLINE_MS} ms after arrival and no schedule slip; a size passes when ALL its undisturbed runs pass AND the "
+                        f"run with a {STALL_MS:.0f} ms host stall injected at frame {STALL_AT_FRAME} is back on its clock within {RECOVERY_FRAMES} "
+                        f"frames with no miss after that; the largest passing size is then held for one run of `confirmation_seconds`"}
 
 
 def distinct_streams_leg(api, torch, ctx, dev, B, K, W, seed=2026, prime=12):
@@ -759,7 +819,8 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--no-realtime", action="store_true", help="skip the paced 10 ms-clock runs through the pipelined host path")
     ap.add_argument("--realtime-seconds", type=float, default=6.0, help="length of one paced run")
-    ap.add_argument("--realtime-runs", type=int, default=3, help="paced runs per batch size (a size passes when all of them do)")
+    ap.add_argument("--realtime-soak-seconds", type=float, default=20.0, help="length of the confirmation run at the capacity found (0: none)")
+    ap.add_argument("--realtime-runs", type=int, default=2, help="paced runs per batch size (a size passes when all of them do)")
     ap.add_argument("--no-distinct", action="store_true", help="skip the timed run on 65 536 streams that are all different")
     ap.add_argument("--no-numa", action="store_true", help="do not bind the rank to the CPUs of its GPU's NUMA node")
     ap.add_argument("--strict", action="store_true", help="bit-exact network mode (slow)")
@@ -936,8 +997,9 @@ def main():
     if not (a.strict or a.no_sustained or a.no_realtime):
         sharding.barrier(dist)
         if world == 1 and B == 65536 and nn_mode == api.NN_MFMA:
-            capacity = realtime_capacity(api, synth, model, local_rank, nn_mode, a.realtime_seconds, a.realtime_runs, log)
-            at_b = [r for r in capacity["paced_runs"] if r.get("streams") == B]
+            capacity = realtime_capacity(api, synth, model, local_rank, nn_mode, a.realtime_seconds, a.realtime_runs, log,
+                                         soak_seconds=a.realtime_soak_seconds)
+            at_b = [r for r in capacity["paced_runs"] if r.get("streams") == B and not r.get("recovery")]
             realtime_rank = at_b[0] if at_b else None
         else:
             try:

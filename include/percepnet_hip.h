@@ -150,6 +150,10 @@ int pn_host_wait(pn_ctx *ctx);               /* every submitted frame delivered 
 /* Non-blocking: how many submitted frames have been DELIVERED (output copy complete) so far; -1 on error.  For callers on a
    real-time clock that timestamp each frame's delivery between arrivals (reference contract: src/main.cpp:30-39). */
 int64_t pn_host_frames_delivered(pn_ctx *ctx);
+/* How the two copy streams (host-to-device, device-to-host) of the pipelined path were obtained, one letter each: "n" a
+   default-priority stream probed to share its hardware queue with neither the compute stream nor the other copy stream, "h" /
+   "l" a high- / low-priority stream (the fallback); "" before the first pn_submit_host_* call.  Diagnostics (bench.py). */
+const char *pn_ctx_pipe_streams(pn_ctx *ctx);
 void *pn_host_alloc(size_t bytes);           /* pinned host memory (hipHostMalloc); NULL on failure */
 /* One host feeding several GPUs: bind the CALLING THREAD to the CPUs of the NUMA node `device` hangs off (sysfs
    /sys/bus/pci/devices/<bdf>/numa_node) — call it in the thread that will own the device BEFORE pn_ctx_create / pn_host_alloc,

@@ -70,6 +70,9 @@ def load_library():
     for name in ("pn_submit_host_f32", "pn_submit_host_i16"):
         getattr(L, name).argtypes = [_vp, _vp, _vp, _vp]
     L.pn_host_wait.argtypes = [_vp]
+    if hasattr(L, "pn_ctx_pipe_streams"):
+        L.pn_ctx_pipe_streams.argtypes = [_vp]
+        L.pn_ctx_pipe_streams.restype = ctypes.c_char_p
     if hasattr(L, "pn_host_frames_delivered"):
         L.pn_host_frames_delivered.argtypes = [_vp]
         L.pn_host_frames_delivered.restype = ctypes.c_int64
@@ -211,6 +214,10 @@ class Context:
     def submit_host_i16_active(self, h_in, h_out, h_gr, ids):
         a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).ravel())
         self._chk(self.L.pn_submit_host_i16_active(self.h, h_in, h_out, h_gr, a.ctypes.data, int(a.size)))
+
+    def pipe_streams(self):
+        """'nn' / 'hl' ...: how the copy streams of the pipelined host path were obtained ('' before the first submit)"""
+        return self.L.pn_ctx_pipe_streams(self.h).decode() if hasattr(self.L, "pn_ctx_pipe_streams") else ""
 
     def host_wait(self):
         self._chk(self.L.pn_host_wait(self.h))

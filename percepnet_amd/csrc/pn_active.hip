@@ -105,3 +105,14 @@ void pn_launch_inactive_save(hipStream_t st, const PnActiveArgs &a, int n) {
 void pn_launch_inactive_fixup(hipStream_t st, const PnActiveArgs &a, int n) {
   if (n > 0) hipLaunchKernelGGL(pn_inactive_fixup_kernel, dim3(n), dim3(256), 0, st, a);
 }
+
+// ---- a kernel that only passes time (pipe_init's queue probe, pn_context.cpp) --------------------------------------
+// One wave that sleeps until `ticks` of the 100 MHz wall clock have gone by.
+__global__ void pn_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int pn_launch_spin(hipStream_t st, long long ticks) {
+  hipLaunchKernelGGL(pn_spin_kernel, dim3(1), dim3(64), 0, st, ticks);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

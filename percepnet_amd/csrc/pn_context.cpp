@@ -109,6 +109,7 @@ struct pn_ctx {
     void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
     float *gr[2] = {nullptr, nullptr};
     int64_t submitted = 0;
+    char kind[3] = {'?', '?', 0};             // how each copy stream was obtained: n (default priority, probed) / h / l (priority stream)
   } pipe;
 };
 
@@ -933,18 +934,84 @@ extern "C" int pn_process_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_ou
 //   d2h stream:                     D2H(t) ......... D2H(t+1)
 // Slot k = t & 1 is reused by frame t+2 only after the host has seen frame t delivered, which also bounds the frames
 // in flight to two.
+// Do `busy` and `cand` share a hardware queue?  A 1 ms sleeper goes to `busy`, then a 64-byte copy to `cand`: on a queue of
+// its own the copy lands while the sleeper runs; on a shared queue it lands after it.
+static int pipe_streams_share(pn_ctx *c, hipStream_t busy, hipStream_t cand, void *d_scratch, void *h_scratch, bool *shared) {
+  hipEvent_t ek, ec;
+  PN_HIP_CHECK(hipEventCreateWithFlags(&ek, hipEventDisableTiming));
+  PN_HIP_CHECK(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+  if (pn_launch_spin(busy, 100000)) { pn_set_error("queue probe: launch failed"); return -1; }
+  PN_HIP_CHECK(hipEventRecord(ek, busy));
+  PN_HIP_CHECK(hipMemcpyAsync(d_scratch, h_scratch, 64, hipMemcpyHostToDevice, cand));
+  PN_HIP_CHECK(hipEventRecord(ec, cand));
+  PN_HIP_CHECK(hipEventSynchronize(ec));
+  *shared = hipEventQuery(ek) == hipSuccess;
+  PN_HIP_CHECK(hipEventSynchronize(ek));
+  PN_HIP_CHECK(hipEventDestroy(ek));
+  PN_HIP_CHECK(hipEventDestroy(ec));
+  (void)c;
+  return 0;
+}
+
+// One copy stream.  how: 'n' default priority unprobed, 'h' / 'l' a priority stream, 'a' (the default) a default-priority
+// stream that shares its queue with none of `others` — up to 6 candidates (the rejected ones stay alive until the end, so
+// that the runtime's least-used-queue choice moves on), else the priority stream `fallback`.
+static int pipe_make_stream(pn_ctx *c, hipStream_t *out, char how, int prio, char fallback, std::initializer_list<hipStream_t> others, char *kind) {
+  if (how == 'h' || how == 'l') {
+    int lo = 0, hi = 0;
+    PN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PN_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, how == 'h' ? hi : lo));
+    *kind = how;
+    return 0;
+  }
+  if (how == 'n') { PN_HIP_CHECK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); *kind = 'n'; return 0; }
+  void *h_scratch = NULL, *d_scratch = NULL;
+  PN_HIP_CHECK(hipHostMalloc(&h_scratch, 64, hipHostMallocDefault));
+  memset(h_scratch, 0, 64);
+  PN_HIP_CHECK(hipMalloc(&d_scratch, 64));
+  std::vector<hipStream_t> rejected;
+  hipStream_t got = nullptr;
+  int rc = 0;
+  for (int attempt = 0; attempt < 6 && !got && !rc; attempt++) {
+    hipStream_t s;
+    PN_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    PN_HIP_CHECK(hipMemcpyAsync(d_scratch, h_scratch, 64, hipMemcpyHostToDevice, s));       // first use of the stream, not timed
+    PN_HIP_CHECK(hipStreamSynchronize(s));
+    bool bad = false;
+    for (hipStream_t o : others) {
+      bool sh = false;
+      if (pipe_streams_share(c, o, s, d_scratch, h_scratch, &sh)) { rc = -1; break; }
+      if (sh) { bad = true; break; }
+    }
+    if (!bad && !rc) got = s; else rejected.push_back(s);
+  }
+  for (hipStream_t s : rejected) hipStreamDestroy(s);
+  hipFree(d_scratch); hipHostFree(h_scratch);
+  if (rc) return rc;
+  if (got) { *out = got; *kind = 'n'; return 0; }
+  PN_HIP_CHECK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
+  *kind = fallback;
+  return 0;
+}
+
 static int pipe_init(pn_ctx *c) {
   pn_ctx::Pipe &P = c->pipe;
   if (P.init) return 0;
-  // The copy streams get the two priority levels the compute stream does not use.  HIP multiplexes the streams of one
+  // Each of the three streams of the pipeline needs a hardware queue of its own.  HIP multiplexes the streams of one
   // priority over a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): in a process that already owns a handful of
-  // streams a copy stream of the same priority lands on the queue of the compute stream and the copy of frame t - 1 then
-  // runs BEHIND the kernels of frame t instead of beside them (measured: 10.6 instead of 9.5 ms per frame at 65 536
-  // streams, profiles/r04q_host_pipeline_queues.log).  Queues of different priorities are never shared.
+  // streams (torch's pools) a copy stream can land on the queue of the compute stream, and the copy of frame t - 1 then
+  // runs BEHIND the kernels of frame t instead of beside them (10.6 instead of 9.5 ms per frame at 65 536 streams,
+  // profiles/r04q_host_pipeline_queues.log).  Queues of different priorities are never shared — but two copy streams at
+  // the non-default priorities cost every kernel of the compute stream ~50 us (back-to-back frames 10.06 instead of
+  // 9.48 ms at 65 536 streams; one priority stream costs nothing: profiles/r05_host_pipeline.log).  So: default-priority
+  // streams, each PROBED against the streams it must not share a queue with (pipe_make_stream), a priority stream only
+  // as the fallback.  PN_PIPE_PRIO = two letters (h2d, d2h) of h / n / l overrides (tools/host_pipeline_probe.py).
   int prio_least = 0, prio_greatest = 0;
   PN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-  PN_HIP_CHECK(hipStreamCreateWithPriority(&P.h2d, hipStreamNonBlocking, prio_greatest));
-  PN_HIP_CHECK(hipStreamCreateWithPriority(&P.d2h, hipStreamNonBlocking, prio_least));
+  const char *pp = getenv("PN_PIPE_PRIO");
+  if (pp && strlen(pp) != 2) pp = NULL;
+  if (pipe_make_stream(c, &P.h2d, pp ? pp[0] : 'a', prio_greatest, 'h', {c->stream}, &P.kind[0])) return -1;
+  if (pipe_make_stream(c, &P.d2h, pp ? pp[1] : 'a', prio_least, 'l', {c->stream, P.h2d}, &P.kind[1])) return -1;
   for (int k = 0; k < 2; k++) {
     PN_HIP_CHECK(hipEventCreateWithFlags(&P.in_ready[k], hipEventDisableTiming));
     PN_HIP_CHECK(hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
@@ -991,6 +1058,8 @@ static int submit_host(pn_ctx *c, const void *h_in, void *h_out, float *h_gr, in
   P.submitted++;
   return 0;
 }
+// "nn" / "hl" / ...: how the two copy streams of the pipelined path were obtained (pipe_init); "" before the first submit
+extern "C" const char *pn_ctx_pipe_streams(pn_ctx *c) { return (c && c->pipe.init) ? c->pipe.kind : ""; }
 extern "C" int pn_submit_host_f32(pn_ctx *c, const float *h_in, float *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 0); }
 extern "C" int pn_submit_host_i16(pn_ctx *c, const int16_t *h_in, int16_t *h_out, float *h_gr) { return submit_host(c, h_in, h_out, h_gr, 1); }
 // The pipelined path with a per-call active set: rows of h_in of skipped streams are ignored; their rows of h_out / h_gr are

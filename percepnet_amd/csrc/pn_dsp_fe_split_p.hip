@@ -36,6 +36,9 @@
 #ifndef PN_FP_DS_DPP
 #define PN_FP_DS_DPP 1                   // pitch_downsample: x[4m - 1] from the neighbouring lane (row rotate) instead of a scalar load
 #endif
+#ifndef PN_FP_ROWS_PRE
+#define PN_FP_ROWS_PRE 1                 // autocorrelation and the final three chains: products formed lane-parallel (fp_chain_rows_pre)
+#endif
 #ifndef PN_FP_DPP_ASM
 #define PN_FP_DPP_ASM 2                  // group-uniform recurrences: DPP adds from inline assembly (no hazard padding on the accumulator)
 #endif
@@ -153,6 +156,60 @@ __device__ __forceinline__ float fp_chain_rows(const float *a, const float *b, i
 #undef FP_CR_MAC
   return acc;
 }
+
+#if PN_FP_ROWS_PRE
+// acc + (lane (this + n) of the row's value of v), one DPP instruction, no hazard padding on acc (see fp_add_bc)
+template <int n>
+__device__ __forceinline__ float fp_add_shl(float acc, float v) {
+  if (n == 0) return acc + v;
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(acc), "n"(n & 15));
+  return r;
+}
+// Consecutive-lag chains with the PRODUCTS formed lane-parallel (round 5): lane k < NL of the group accumulates
+// sum_{j<N} a[j] * b[j + k] — the same chain, product by product in j order — but the multiply for (lag k, step j0 + i) is done by
+// lane k + NL i (i < S = 16 / NL): one v_mul serves S steps of all NL chains, and step i adds lane k + NL i's product to lane k
+// through row_shl inside the add.  Per S steps: two per-lane ds_read_b32, one multiply, S adds (fp_chain_rows: per 12 steps 3
+// ds_read_b128 + 1 ds_read_b32 + 12 multiplies + 12 adds).  Products past j = N - 1 are +0 (a sum that starts at +0 never is -0).
+template <int N, int NL>
+__device__ __forceinline__ float fp_chain_rows_pre(const float *a, const float *b, int l, float acc) {
+  constexpr int S = 16 / NL, NF = N / S, U = 4, NT = NF / U;       // NF full blocks of S steps, U blocks per trip
+  const int i = l / NL, k = l - NL * i;
+  const bool on = i < S;
+  const float *pa = a + (on ? i : 0), *pb = b + (on ? i + k : 0);
+  float xa[U], xb[U], ya[U], yb[U];
+#define FP_RP_LOAD(av, bv, blk0) do { _Pragma("unroll") for (int t_ = 0; t_ < U; t_++) { (av)[t_] = pa[S * ((blk0) + t_)]; (bv)[t_] = pb[S * ((blk0) + t_)]; } } while (0)
+#define FP_RP_ADDS(q) do { if (S >= 1) acc = fp_add_shl<0>(acc, q); if (S >= 2) acc = fp_add_shl<NL>(acc, q); if (S >= 3) acc = fp_add_shl<2 * NL>(acc, q); \
+                           if (S >= 4) acc = fp_add_shl<3 * NL>(acc, q); if (S >= 5) acc = fp_add_shl<4 * NL>(acc, q); } while (0)
+#define FP_RP_MAC(av, bv) do { float q_[U]; _Pragma("unroll") for (int t_ = 0; t_ < U; t_++) { q_[t_] = (av)[t_] * (bv)[t_]; asm("" : "+v"(q_[t_])); } \
+                               _Pragma("unroll") for (int t_ = 0; t_ < U; t_++) FP_RP_ADDS(q_[t_]); } while (0)
+  FP_RP_LOAD(xa, xb, 0);
+#pragma unroll 1
+  for (int t = 0; t + 1 < NT; t += 2) {
+    FP_RP_LOAD(ya, yb, U * (t + 1));
+    FP_FENCE();
+    FP_RP_MAC(xa, xb);
+    FP_RP_LOAD(xa, xb, U * (t + 2 < NT ? t + 2 : NT - 1));      // the last trip re-reads a block it does not use
+    FP_FENCE();
+    FP_RP_MAC(ya, yb);
+  }
+  if (NT & 1) FP_RP_MAC(xa, xb);                                   // (requested by the last trip, or the only trip)
+  // remaining full blocks and the partial one
+#pragma unroll
+  for (int blk = NT * U; blk * S < N; blk++) {
+    const bool in = blk * S + i < N;
+    float q = pa[in ? S * blk : 0] * pb[in ? S * blk : 0];
+    q = in ? q : 0.f;
+    asm("" : "+v"(q));
+    FP_DPP_SETTLE("+v"(q));
+    FP_RP_ADDS(q);
+  }
+#undef FP_RP_LOAD
+#undef FP_RP_ADDS
+#undef FP_RP_MAC
+  return acc;
+}
+#endif
 
 // Two chains sharing a[], per-lane operands at ARBITRARY lags (remove_doubling's 28 + 2 inner products): acc1 += a . b1,
 // acc2 += a . b2.  Every lane reads its operands as 8-byte ALIGNED pairs (ds_read_b64: 64 banks, half the instructions)
@@ -431,7 +488,11 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
       float ac[5];
       {
         const int lag = l < 4 ? l : 4;
+#if PN_FP_ROWS_PRE
+        float ack = fp_chain_rows_pre<860, 5>(raw, raw, l, 0.f);
+#else
         float ack = fp_chain_rows<860>(raw, raw, l, 0.f);     // lane k <= 4: sum_i raw[i] * raw[i + k]; lanes > 4 are never read
+#endif
         FE_MARK(10);  // autocorrelation chain
         float d = 0;
         for (int i = lag + 860; i < 864; i++) d = d + raw[i] * raw[i - lag];
@@ -792,7 +853,11 @@ __global__ __launch_bounds__(FP_THREADS, 2) void pn_fe_pitch_kernel(
         if (best_yy <= best_xy) pg = 1.0f; else pg = best_xy / (best_yy + 1);
         // xcorr[k] = x . (x - (T + k - 1)), k = 0..2 (pitch.cpp:511-512): lane lam holds k = 2 - lam, so that the operands of
         // consecutive lanes are consecutive floats (x[j - Tsel - 1 + lam]) and one row read serves 12 steps
+#if PN_FP_ROWS_PRE
+        const float xc = fp_chain_rows_pre<480, 3>(x, x - (Tsel + 1), l, 0.f);
+#else
         const float xc = fp_chain_rows<480>(x, x - (Tsel + 1), l, 0.f);
+#endif
         FE_MARK(12);  // remove_doubling: decision + the three final inner products
         const float xc0 = __shfl(xc, gb + 2), xc1 = __shfl(xc, gb + 1), xc2 = __shfl(xc, gb);
         int off2;

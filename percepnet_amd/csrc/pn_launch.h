@@ -48,6 +48,7 @@ struct PnActiveArgs {
   long long B, Bp, t, tn;                            // t / tn: the counters of the tick the fix-up follows
 };
 void pn_launch_inactive_save(hipStream_t st, const PnActiveArgs &a, int n);
+int pn_launch_spin(hipStream_t st, long long ticks);     // one wave asleep for `ticks` of the 100 MHz wall clock (queue probe)
 void pn_launch_inactive_fixup(hipStream_t st, const PnActiveArgs &a, int n);
 // training-feature path (pn_targets.hip)
 void pn_launch_targets(hipStream_t st, const PnTables *T, int n_pairs, const float *ex_clean, const float *ex_noisy,

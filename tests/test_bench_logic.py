@@ -45,17 +45,22 @@ def test_capacity_search_bisects_and_reports_the_next_size(monkeypatch):
 
     calls = []
 
-    def fake_paced(limit, flaky=None):
-        def f(api, synth, model, dev, b, mode, seconds, ctx=None):
-            calls.append(b)
-            ok = b <= limit and not (b == flaky and calls.count(b) == 2)
+    def fake_paced(limit, flaky=None, recover_limit=10 ** 9, soak_limit=10 ** 9):
+        def f(api, synth, model, dev, b, mode, seconds, ctx=None, stall=None):
+            calls.append((b, seconds, stall))
+            if stall is not None:                                                    # the disturbed run of a size
+                ok = b <= min(limit, recover_limit)
+                return {"streams": b, "met_contract": ok, "recovery": {"frames_to_recover": 120 if ok else None, "recovered": ok}}
+            n = sum(1 for c in calls if c[0] == b and c[2] is None)
+            ok = b <= limit and not (b == flaky and n == 2) and not (seconds >= 20 and b > soak_limit)
             return {"streams": b, "deadline_misses": 0 if ok else 7, "delivery_latency_ms": {"p99": 12.0 if ok else 80.0}, "met_contract": ok}
         return f
 
     monkeypatch.setattr(bench, "paced_realtime", fake_paced(67700))
     r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
-    assert r["realtime_streams_p99"] == 67584 and r["next_size"] == {"streams": 68096, "runs": 3, "passed": 0}
+    assert r["realtime_streams_p99"] == 67584 and r["next_size"] == {"streams": 68096, "runs": 3, "passed": 0, "recovered": [False]}
     assert r["sizes"]["67584"]["passed"] == 3 and set(r["sizes"]) == {"65536", "67584", "68096", "68608"}
+    assert r["sizes"]["67584"]["stall_recovery"] == [{"frames_to_recover": 120, "recovered": True}]
     calls.clear()
     monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9))
     r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
@@ -63,11 +68,23 @@ def test_capacity_search_bisects_and_reports_the_next_size(monkeypatch):
     calls.clear()
     monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9, flaky=67584))          # one run of three fails at 67 584
     r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
-    assert r["realtime_streams_p99"] == 67072 and r["next_size"] == {"streams": 67584, "runs": 3, "passed": 2}
+    assert r["realtime_streams_p99"] == 67072 and r["next_size"] == {"streams": 67584, "runs": 3, "passed": 2, "recovered": [True]}
     calls.clear()
     monkeypatch.setattr(bench, "paced_realtime", fake_paced(60000))
     r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 1, lambda m: None)
     assert r["realtime_streams_p99"] == 57344 and r["next_size"]["streams"] == 65536
+    # every undisturbed run passes everywhere, but only sizes <= 66 600 catch up after the injected stall
+    calls.clear()
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9, recover_limit=66600))
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    assert r["realtime_streams_p99"] == 66560 and r["next_size"] == {"streams": 67072, "runs": 2, "passed": 2, "recovered": [False]}
+    # the confirmation run: 67 584 passes its 1 s runs and fails the 20 s one; the search steps down the grid to the next size that
+    # passes its own runs and the long one
+    calls.clear()
+    monkeypatch.setattr(bench, "paced_realtime", fake_paced(67700, soak_limit=66600))
+    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None, soak_seconds=20.0)
+    assert r["realtime_streams_p99"] == 66560 and [x["met_contract"] for x in r["confirmation_runs"]] == [False, False, True]
+    assert r["next_size"]["streams"] == 67072
 
 
 def test_profile_summaries_keep_only_the_steady_state_frames(tmp_path):
