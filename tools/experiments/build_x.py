@@ -1,6 +1,8 @@
 """Build lib/variants/<name>/libpercepnet_hip.so with tools/experiments/pitch_x.hip in place of csrc/pn_dsp_fe_split_p.hip (the other
 objects come from the default build), so that pitch-kernel experiments do not touch the kernels the committed profiles are stamped for.
-    python tools/experiments/build_x.py <name> [-DFLAG ...]"""
+    cp percepnet_amd/csrc/pn_dsp_fe_split_p.hip tools/experiments/pitch_x.hip      (the working copy is not tracked)
+    python tools/experiments/build_x.py <name> [-DFLAG ...]
+then PERCEPNET_LIB=percepnet_amd/lib/variants/<name>/libpercepnet_hip.so python tools/fp_variants.py / tools/fe_ab.py on the GPU box."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
