@@ -116,6 +116,30 @@ class Oracle:
         self.lib.pno_destroy(st)
         return feat, sil
 
+    def stages(self, x):
+        """Per-frame DSP stage taps of one stream (float samples, the /32768 convention of the CLI): dict of X, P, Y [n, 481] complex64,
+        Ex, Ep, Exp, Ey [n, 34], period [n], feat [n, 70], silence [n], comb_buf [n, 5760] (the history AFTER each frame)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // 480
+        L = self.lib
+        L.pno_frame_stages.argtypes = [ctypes.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f]
+        L.pno_frame_stages.restype = ctypes.c_int
+        L.pno_state_comb_buf.argtypes = [ctypes.c_void_p, c_f]
+        st = L.pno_create(self.model)
+        o = {k: np.zeros((n, 481, 2), np.float32) for k in ("X", "P", "Y")}
+        o.update({k: np.zeros((n, 34), np.float32) for k in ("Ex", "Ep", "Exp", "Ey")})
+        o["period"] = np.zeros(n, np.int32); o["feat"] = np.zeros((n, 70), np.float32); o["silence"] = np.zeros(n, np.int32)
+        o["comb_buf"] = np.zeros((n, 5760), np.float32)
+        for t in range(n):
+            o["silence"][t] = L.pno_frame_stages(st, _fp(x[t * 480:]), _fp(o["X"][t]), _fp(o["P"][t]), _fp(o["Y"][t]), _fp(o["Ex"][t]),
+                                                 _fp(o["Ep"][t]), _fp(o["Exp"][t]), _fp(o["Ey"][t]),
+                                                 o["period"][t:].ctypes.data_as(c_i), _fp(o["feat"][t]))
+            L.pno_state_comb_buf(st, _fp(o["comb_buf"][t]))
+        L.pno_destroy(st)
+        for k in ("X", "P", "Y"):
+            o[k] = o[k].view(np.complex64)[..., 0]
+        return o
+
     def train_run(self, speech, noisy, want_test_pcm=True):
         """The `percepNet` training binary on in-memory PCM -> (records [count,138], test_output [count,480])."""
         speech = np.ascontiguousarray(speech, dtype=np.int16); noisy = np.ascontiguousarray(noisy, dtype=np.int16)

@@ -620,6 +620,33 @@ int pno_frame_features(pno_state *st, const float *in, float *feat70) {
   return a.silence;
 }
 
+/* Per-stage taps for the GPU per-stage parity tests: one frame of compute_frame_features
+   (denoise.cpp:372-434) + compute_lookahead_band_energy (498-506) + create_features (487-496), DSP only — the DSP state
+   (comb_buf, last_period, last_gain) never depends on the network, so a state driven through this function evolves like
+   one driven through pno_process_frame.  X = spectrum of the frame being enhanced (frame_analysis 333-346 through
+   kiss_fft.cpp:566-586), P = spectrum of the comb-filtered signal (416-427), Y = look-ahead spectrum; all [481] re,im.
+   Any output pointer may be NULL.  Returns the silence flag. */
+int pno_frame_stages(pno_state *st, const float *in, float *X_ri, float *P_ri, float *Y_ri, float *Ex, float *Ep,
+                     float *Exp, float *Ey, int *period, float *feat70) {
+  frame_ana a; cpx Y[FREQ]; float ey[NB], f[70];
+  frame_features(st, &a, in);
+  make_features(st, &a, f);
+  window_fft(Y, st->comb_buf + COMB_BUF - WINDOW);
+  band_energy(ey, Y);
+  if (X_ri) memcpy(X_ri, a.X, sizeof(a.X));
+  if (P_ri) memcpy(P_ri, a.P, sizeof(a.P));
+  if (Y_ri) memcpy(Y_ri, Y, sizeof(Y));
+  if (Ex) memcpy(Ex, a.Ex, sizeof(a.Ex));
+  if (Ep) memcpy(Ep, a.Ep, sizeof(a.Ep));
+  if (Exp) memcpy(Exp, a.Exp, sizeof(a.Exp));
+  if (Ey) memcpy(Ey, ey, sizeof(ey));
+  if (period) *period = st->last_period;
+  if (feat70) memcpy(feat70, f, sizeof(f));
+  return a.silence;
+}
+/* the stream's comb_buf (denoise.cpp:32: 5760 samples, oldest first) */
+void pno_state_comb_buf(const pno_state *st, float *dst5760) { memcpy(dst5760, st->comb_buf, sizeof(st->comb_buf)); }
+
 /* rnnoise_process_frame denoise.cpp:508-547 */
 static void post_filtering(float *g, const float *Ey);
 

@@ -55,6 +55,10 @@ float pno_remove_doubling(const float *buf864, int *T0, int prev_period, float p
 void pno_compute_rnn(pno_state *st, float *g, float *r, const float *feat70);
 /* features of one frame without running the NN: returns silence flag; feat70 written */
 int pno_frame_features(pno_state *st, const float *in, float *feat70);
+/* per-stage taps of one frame, DSP only (no NN): X, P, Y [481][2]; Ex, Ep, Exp, Ey [34]; any pointer may be NULL */
+int pno_frame_stages(pno_state *st, const float *in, float *X_ri, float *P_ri, float *Y_ri, float *Ex, float *Ep,
+                     float *Exp, float *Ey, int *period, float *feat70);
+void pno_state_comb_buf(const pno_state *st, float *dst5760);
 float pno_tansig(float x);
 float pno_sigmoid(float x);
 void pno_dense(const float *bias, const float *w, int nin, int nn, int act, float *out, const float *in);

@@ -10,7 +10,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench  # noqa: E402
+import realtime_capacity as rtc  # noqa: E402
 
 
 def test_spec_out_algorithmic_bytes_follow_from_the_runs_periods():
@@ -56,33 +58,33 @@ def test_capacity_search_bisects_and_reports_the_next_size(monkeypatch):
             return {"streams": b, "deadline_misses": 0 if ok else 7, "delivery_latency_ms": {"p99": 12.0 if ok else 80.0}, "met_contract": ok}
         return f
 
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(67700))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(67700))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
     assert r["realtime_streams_p99"] == 67584 and r["next_size"] == {"streams": 68096, "runs": 3, "passed": 0, "recovered": [False]}
     assert r["sizes"]["67584"]["passed"] == 3 and set(r["sizes"]) == {"65536", "67584", "68096", "68608"}
     assert r["sizes"]["67584"]["stall_recovery"] == [{"frames_to_recover": 120, "recovered": True}]
     calls.clear()
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(10 ** 9))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
     assert r["realtime_streams_p99"] == 69632 and r["next_size"] is None
     calls.clear()
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9, flaky=67584))          # one run of three fails at 67 584
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(10 ** 9, flaky=67584))          # one run of three fails at 67 584
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 3, lambda m: None)
     assert r["realtime_streams_p99"] == 67072 and r["next_size"] == {"streams": 67584, "runs": 3, "passed": 2, "recovered": [True]}
     calls.clear()
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(60000))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 1, lambda m: None)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(60000))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 1, lambda m: None)
     assert r["realtime_streams_p99"] == 57344 and r["next_size"]["streams"] == 65536
     # every undisturbed run passes everywhere, but only sizes <= 66 600 catch up after the injected stall
     calls.clear()
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(10 ** 9, recover_limit=66600))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(10 ** 9, recover_limit=66600))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
     assert r["realtime_streams_p99"] == 66560 and r["next_size"] == {"streams": 67072, "runs": 2, "passed": 2, "recovered": [False]}
     # the confirmation run: 67 584 passes its 1 s runs and fails the 20 s one; the search steps down the grid to the next size that
     # passes its own runs and the long one
     calls.clear()
-    monkeypatch.setattr(bench, "paced_realtime", fake_paced(67700, soak_limit=66600))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None, soak_seconds=20.0)
+    monkeypatch.setattr(rtc, "paced_realtime", fake_paced(67700, soak_limit=66600))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None, soak_seconds=20.0)
     assert r["realtime_streams_p99"] == 66560 and [x["met_contract"] for x in r["confirmation_runs"]] == [False, False, True]
     assert r["next_size"]["streams"] == 67072
 
@@ -92,16 +94,16 @@ def test_transient_runs_are_one_recovered_burst_and_cost_an_extra_run(monkeypatc
     capacity search answers ONE transient at a size with one more undisturbed run (which must be clean), two failures fail the size."""
     n = 600
     lat = np.full(n, 12.0); missed = np.zeros(n, bool)
-    assert bench.transient_burst(missed, lat, 2.0) == (False, None)                           # nothing late
+    assert rtc.transient_burst(missed, lat, 2.0) == (False, None)                           # nothing late
     lat[200:230] = 35.0; missed[200:210] = True
-    assert bench.transient_burst(missed, lat, 2.0) == (True, [200, 229])                      # one 30-frame burst, recovered
-    assert bench.transient_burst(missed, lat, 40.0)[0] is False                               # ... but the run ended behind its clock
+    assert rtc.transient_burst(missed, lat, 2.0) == (True, [200, 229])                      # one 30-frame burst, recovered
+    assert rtc.transient_burst(missed, lat, 40.0)[0] is False                               # ... but the run ended behind its clock
     lat2 = lat.copy(); lat2[500:520] = 30.0
-    assert bench.transient_burst(missed, lat2, 2.0)[0] is False                               # two bursts 300 frames apart
+    assert rtc.transient_burst(missed, lat2, 2.0)[0] is False                               # two bursts 300 frames apart
     lat3 = np.full(n, 12.0); lat3[585:] = 40.0
-    assert bench.transient_burst(np.zeros(n, bool), lat3, 2.0)[0] is False                    # still late at the end of the run
+    assert rtc.transient_burst(np.zeros(n, bool), lat3, 2.0)[0] is False                    # still late at the end of the run
     lat4 = lat.copy(); lat4[300] = np.nan
-    assert bench.transient_burst(missed, lat4, 2.0)[0] is False                               # a frame that never came out
+    assert rtc.transient_burst(missed, lat4, 2.0)[0] is False                               # a frame that never came out
 
     class FakeCtx:
         def __init__(self, *a, **k): pass
@@ -124,16 +126,81 @@ def test_transient_runs_are_one_recovered_burst_and_cost_an_extra_run(monkeypatc
         return f
 
     every = {65536 + 512 * k for k in range(9)}
-    monkeypatch.setattr(bench, "paced_realtime", fake({65536: ["ok", "transient"], 67584: ["fail"], 66560: ["fail"], 66048: ["fail"]}))
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
-    assert r["realtime_streams_p99"] == 65536
-    assert r["sizes"]["65536"] == dict(r["sizes"]["65536"], runs=3, passed=2, transient_runs=1)     # the extra run was made and was clean
-    monkeypatch.setattr(bench, "paced_realtime", fake({b: ["transient", "ok", "transient"] for b in every}))   # the extra run fails too
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    # STRICT rule (round-5 verdict item 4): a transient run is a label, it is not forgiven — 65 536 with one transient of two runs is
+    # NOT the strict capacity (the search falls back), it is the figure "with one forgiven burst" (the extra run was made and was clean)
+    monkeypatch.setattr(rtc, "paced_realtime", fake({65536: ["ok", "transient"], 67584: ["fail"], 66560: ["fail"], 66048: ["fail"]}))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    assert r["realtime_streams_p99"] == 65024 and r["realtime_streams_with_one_forgiven_burst"] == 65536
+    assert r["sizes"]["65536"] == dict(r["sizes"]["65536"], runs=3, passed=2, transient_runs=1, strict=False, with_one_forgiven_burst=True)
+    assert r["sizes"]["65024"]["strict"] is True
+    monkeypatch.setattr(rtc, "paced_realtime", fake({b: ["transient", "ok", "transient"] for b in every}))   # the extra run fails too
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
     assert r["realtime_streams_p99"] == 65024 and r["sizes"]["65536"]["runs"] == 3 and r["sizes"]["65536"]["passed"] == 1
-    monkeypatch.setattr(bench, "paced_realtime", fake({b: ["transient", "transient"] for b in every}))          # two transients: no extra run
-    r = bench.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
+    assert r["realtime_streams_with_one_forgiven_burst"] == 65024
+    monkeypatch.setattr(rtc, "paced_realtime", fake({b: ["transient", "transient"] for b in every}))          # two transients: no extra run
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None)
     assert r["realtime_streams_p99"] == 65024 and r["sizes"]["65536"]["runs"] == 2
+    # bench.py's default: ONE size and one fallback — no grid search
+    monkeypatch.setattr(rtc, "paced_realtime", fake({}))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None, grid=[65536], fallback=(61440,))
+    assert r["realtime_streams_p99"] == 65536 and set(r["sizes"]) == {"65536"} and r["next_size"] is None
+    monkeypatch.setattr(rtc, "paced_realtime", fake({65536: ["ok", "fail"]}))
+    r = rtc.realtime_capacity(FakeApi, None, None, 0, 0, 1.0, 2, lambda m: None, grid=[65536], fallback=(61440,))
+    assert r["realtime_streams_p99"] == 61440 and set(r["sizes"]) == {"61440", "65536"} and r["realtime_streams_with_one_forgiven_burst"] == 61440
+
+
+def test_stall_run_verdict_checks_deliveries_after_the_recovery_point():
+    """Advisor (round 5): the disturbed run's verdict used to be the recovery of the SUBMIT clock alone.  stall_verdict's recovery
+    point is the frame after the LAST disturbed frame (late submit, back-pressure, late or missing delivery): the device queue drains
+    for some frames after the submit clock is back, and those frames count."""
+    n, at = 600, 100
+    backlog = np.zeros(n); backlog[at:at + 60] = np.linspace(0.05, 0.001, 60)        # 50 ms behind, submit clock back 60 frames later
+    late = np.zeros(n); late[at:at + 30] = 0.002
+    lat = np.full(n, 11.0); lat[at:at + 70] = 45.0                                     # ... deliveries late for 10 frames more
+    v = rtc.stall_verdict(backlog, late, lat, at, 1.0)
+    assert v["recovered"] is True and v["frames_to_recover"] == 70 and v["frames_to_recover_submit_clock"] == 60
+    assert v["disturbed_frames"] == 70 and v["clean_frames_after_recovery"] == n - at - 70 and v["delivery_p99_ms_after_recovery"] == 11.0
+    lat_bad = lat.copy(); lat_bad[450:455] = 40.0                                      # late again 350 frames after the stall: past the limit
+    v = rtc.stall_verdict(backlog, late, lat_bad, at, 1.0)
+    assert v["recovered"] is False and v["frames_to_recover"] == 355
+    lat_nan = lat.copy(); lat_nan[590] = np.nan                                        # a frame near the end never came out
+    assert rtc.stall_verdict(backlog, late, lat_nan, at, 1.0)["recovered"] is False
+    late2 = late.copy(); late2[520] = 0.001                                            # a back-pressure miss long after
+    assert rtc.stall_verdict(backlog, late2, lat, at, 1.0)["recovered"] is False
+    never = np.zeros(n); never[at:] = 0.02
+    v = rtc.stall_verdict(never, late, lat, at, 1.0)
+    assert v["recovered"] is False and v["frames_to_recover_submit_clock"] is None
+    assert rtc.stall_verdict(backlog, late, lat, at, 25.0)["recovered"] is False        # ended behind its clock
+    early = lat.copy(); early[40] = 30.0                                               # a late frame BEFORE the stall: not a clean run
+    assert rtc.stall_verdict(backlog, late, early, at, 1.0)["recovered"] is False
+
+
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_the_printed_line_is_compact_and_complete():
+    """Round-5 verdict item 1: BENCH_r05.json came back `parsed: null` because bench.py printed a 30-38 KB line.  The printed line is
+    built by compact_line() from the full record: here from RECORDED full records (round 5's own lines, the largest ones that exist) —
+    under 8 KB (in fact under 4), every contract key, roofline and cpu_baseline objects with their required fields."""
+    for name in ("r05_bench.json", "r05_bench_third_box.json", "r05_bench_fp16.json", "r05_bench_force_dist_rccl.json"):
+        d = json.loads([l for l in open(os.path.join(ROOT, "profiles", name)) if l.startswith("{")][-1])
+        d.setdefault("cpu_baseline", {"value": 30.0, "unit": "streams", "frames_per_s": 3000.0, "frames_per_s_one_core": 540.0, "cores": 128,
+                                      "kind": "reference", "sample": "x" * 400})
+        line = bench.compact_line(d, "gpurun_out/bench_detail.json")
+        assert "\n" not in line and len(line) < 4096 < bench.LINE_LIMIT, (name, len(line))
+        r = json.loads(line)
+        for k in REQUIRED_LINE_KEYS:
+            assert k in r, (name, k)
+        assert set(r["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and r["roofline"]["bound"] in ("hbm", "mfma")
+        assert set(r["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and len(r["cpu_baseline"]["sample"]) <= 160
+        assert "workload" in r["config"] and "model" not in r["config"]
+        assert r["value"] == d["value"] and r["ms_per_step"] == d["ms_per_step"] and r["detail"] == "gpurun_out/bench_detail.json"
+        assert "paced_runs" not in line and "ranks" not in r                      # the bulk stays in the detail file
+    # a pathological record (hundreds of sizes) still yields a line under the limit: optional objects are dropped, the contract stays
+    d["realtime"] = {"sizes": {str(60000 + k): {"runs": 2, "passed": 2, "transient_runs": 0, "strict": True} for k in range(400)}}
+    line = bench.compact_line(d, None)
+    assert len(line) <= bench.LINE_LIMIT and all(k in json.loads(line) for k in REQUIRED_LINE_KEYS)
 
 
 def test_profile_summaries_keep_only_the_steady_state_frames(tmp_path):

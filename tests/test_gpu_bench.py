@@ -12,14 +12,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+             "data", "config")
+
+
 def _bench(*args):
+    """Runs bench.py; checks the ONE printed line (the driver's record: compact, complete, agreeing with the full record) and returns
+    the full record from the detail file the line points at."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
-                         timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as d:
+        detail = os.path.join(d, "detail.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail-out", detail, *args], capture_output=True, text=True,
+                             timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and out.stdout.rstrip().endswith(lines[0]), out.stdout[-2000:]
+        assert len(lines[0]) < 8192, len(lines[0])
+        line = json.loads(lines[0])
+        full = json.load(open(detail))
+    for k in LINE_KEYS:
+        assert k in line and line[k] == (full[k] if k != "config" else {c: full[k][c] for c in line[k]}), k
+    if "roofline" in full:
+        assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["roofline"]["bound"] in ("mfma", "hbm")
+        assert set(line["roofline"]) >= {"achieved", "peak", "unit", "traffic"}
+    if "cpu_baseline" in full:
+        assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["kind"] == full["cpu_baseline"]["kind"]
+    return full
 
 
 def test_single_rank_line_has_measured_parity_and_roofline():
@@ -38,6 +57,7 @@ def test_single_rank_line_has_measured_parity_and_roofline():
     assert r["realtime_all_ranks"]["all_ranks_met_every_deadline"] is True and r["realtime_streams_p99"] == 2048
     assert "value_note" in r
     assert r["config"]["distributed"].startswith("none")
+    assert "g|r rows out" in r["config"]["io"]                     # the tap rows are copied out inside the timed region
     assert r["sustained"]["steps"] >= 8 and r["sustained"]["seconds"] >= 0.3 and r["sustained"]["value"] > 0
     assert r["config"]["kernel_families"]["gru"] == "batch" and r["config"]["kernel_families"]["dense"] == "small"   # 2048 streams
     for k in ("fe_spec_in", "fe_pitch", "fe_spec_out", "backend"):       # one roofline object per DSP kernel
@@ -54,13 +74,14 @@ def test_single_rank_line_has_measured_parity_and_roofline():
 
 
 def test_paced_real_time_run_through_the_pipelined_host_path():
-    """bench.paced_realtime: frames arrive on the host every 10 ms and go through pn_submit_host_i16 (copy-in / compute /
+    """tools/realtime_capacity.py paced_realtime: frames arrive on the host every 10 ms and go through pn_submit_host_i16 (copy-in / compute /
     copy-out on three streams, each copy stream probed to have a hardware queue of its own).  A small batch must meet every deadline, the
     submit call must return in well under a period, and the serial host call (copy + frame + copy) is reported for scale.
     The process owns other streams when it runs (torch's, a second context's), as bench.py's does."""
     import torch
     sys.path.insert(0, ROOT)
-    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import realtime_capacity as bench
     from percepnet_amd import api, synth, weights
     model = api.Model(weights.default_blob(1234))
     side = [torch.cuda.Stream() for _ in range(4)]          # noqa: F841 — streams that compete for HIP's hardware queues
@@ -71,6 +92,8 @@ def test_paced_real_time_run_through_the_pipelined_host_path():
     d = bench.paced_realtime(api, synth, model, 0, 4096, api.NN_MFMA, seconds=0.8, stall=(10, 40.0))
     other.close()
     assert d["recovery"]["recovered"] is True and 1 <= d["recovery"]["frames_to_recover"] <= 12 and d["met_contract"] is True
+    assert d["recovery"]["clean_frames_after_recovery"] >= 20 and 0 < d["recovery"]["delivery_p99_ms_after_recovery"] <= 20.0
+    assert d["recovery"]["frames_to_recover_submit_clock"] <= d["recovery"]["frames_to_recover"]
     assert d["deadline_misses"] >= 1                        # the stall itself is a missed deadline: it is visible, not hidden
     # the copy streams: default priority and probed ("n"), or the priority fallback ("h" / "l"); back to back the pipeline runs well
     # inside a period at this size

@@ -53,6 +53,34 @@ def test_strict_mode_bit_exact_pcm_and_taps(model, oracle):
     ctx.close()
 
 
+def test_hip_path_straight_against_the_compiled_reference(model, blob):
+    """ONE hop: the HIP path against the reference ITSELF (oracle/_ref/libpercepnet_ref.so = the untouched sources of
+    /root/reference/src compiled in place by oracle/Makefile; the .so travels to the GPU box), not against the restatement:
+    rnnoise_process_frame as percepNet_run drives it (denoise.cpp:508-547, main.cpp:30-39).  8 streams x 100 frames — voiced, loud
+    (non-silent branch), burst + digital silence, two-tone.  STRICT: bit-equal PCM and g,r.  MFMA: <= 1 LSB, |dg,r| <= 2e-5."""
+    from oracle import oracle as orc
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref/libpercepnet_ref.so did not travel to this box")
+    ref = orc.Reference(blob)
+    streams = (0, 1, 3, 7, 13, 23, 27, 33)
+    pcm = np.stack([synth.synth_stream(s, 100) for s in streams])
+    assert {synth.stream_kind(s) for s in streams} == {"voiced", "loud", "bursts", "twotone"}
+    ro, rg = zip(*(ref.run_pcm(pcm[i]) for i in range(len(streams))))
+    ro, rg = np.stack(ro), np.stack(rg)
+    ctx = api.Context(model, len(streams), nn_mode=api.NN_STRICT)
+    out, gr = ctx.run_pcm(pcm)
+    ctx.close()
+    assert np.array_equal(out, ro)
+    assert np.array_equal(gr.view(np.uint32), rg.view(np.uint32))
+    ctx = api.Context(model, len(streams), nn_mode=api.NN_MFMA)
+    out, gr = ctx.run_pcm(pcm)
+    ctx.close()
+    d = np.abs(out.astype(np.int32) - ro.astype(np.int32))
+    assert d.max() <= PCM_TOL_LSB, d.max()
+    assert np.abs(gr - rg).max() <= GR_TOL
+    assert np.abs(ro.astype(np.int32)).max() > 1000 and (ro[2] != 0).any()       # the loud stream is not silence at the output
+
+
 def test_postfilter_option(model, oracle):
     """the optional envelope post-filter (reference post_filtering, denoise.cpp:216-250) between
     the g/r tap and pitch_filter.  The network and its tap are untouched (bit-identical, STRICT); the PCM follows the

@@ -141,6 +141,53 @@ def test_oracle_stages_vs_compiled_reference(blob, oracle):
     assert ga.min() < 0.02 and ga.max() > 0.98
 
 
+@pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (no /root/reference)")
+def test_stage_taps_vs_compiled_reference_stage_functions(blob, oracle):
+    """oracle.stages() (pno_frame_stages: the yardstick of tests/test_gpu_stages.py) pinned to the COMPILED REFERENCE's own stage
+    functions: from the oracle's comb_buf tap, the window (reference tables), ref_fft960 (kiss_fft.cpp:566-586), compute_band_energy
+    / compute_band_corr (denoise.cpp:89-160) and the comb filter (denoise.cpp:416-422, float32 mul then add in k order) are
+    recomputed through oracle/_ref and must equal the taps bit for bit."""
+    ref = Reference(blob)
+    _, _, hw, hann, _ = oracle.tables()
+    win = np.concatenate([hw, hw[::-1]]).astype(np.float32)
+
+    def ref_spectrum(x960):
+        z = np.zeros((960, 2), np.float32); z[:, 0] = x960 * win
+        o = np.zeros_like(z)
+        ref.lib.ref_fft960(_fp(z), _fp(o))
+        return o[:481].copy()
+
+    def ref_bands(X, P=None):
+        e = np.zeros(34, np.float32)
+        if P is None:
+            ref.lib.ref_band_energy(_fp(e), _fp(X))
+        else:
+            ref.lib.ref_band_corr(_fp(e), _fp(X), _fp(P))
+        return e
+
+    def ri(c):                                        # complex64 [481] -> float32 [481, 2]
+        return np.ascontiguousarray(c).view(np.float32).reshape(481, 2)
+
+    for s in (3, 7, 13):
+        x = synth.synth_stream(s, 24).astype(np.float32) / np.float32(32768.0)
+        st = oracle.stages(x)
+        for t in (0, 5, 11, 17, 23):
+            cb = st["comb_buf"][t]
+            X = ref_spectrum(cb[2400:3360]); Y = ref_spectrum(cb[4800:5760])
+            assert np.array_equal(X.view(np.uint32), ri(st["X"][t]).view(np.uint32)), (s, t)
+            assert np.array_equal(Y.view(np.uint32), ri(st["Y"][t]).view(np.uint32)), (s, t)
+            T0 = int(st["period"][t])
+            p = np.zeros(960, np.float32)
+            for k in range(-3, 4):
+                p = p + cb[2400 - T0 * k:2400 - T0 * k + 960] * hann[k + 3]
+            P = ref_spectrum(p)
+            assert np.array_equal(P.view(np.uint32), ri(st["P"][t]).view(np.uint32)), (s, t)
+            assert np.array_equal(ref_bands(X).view(np.uint32), st["Ex"][t].view(np.uint32))
+            assert np.array_equal(ref_bands(P).view(np.uint32), st["Ep"][t].view(np.uint32))
+            assert np.array_equal(ref_bands(Y).view(np.uint32), st["Ey"][t].view(np.uint32))
+        assert np.abs(st["X"]).max() > 0
+
+
 # ---- SURVEY 8(f) row 1: the training-feature binary (train(), denoise.cpp:603-787) -------------------
 def test_train_oracle_matches_golden_records(oracle, golden_dir):
     """Golden = the compiled reference's train() run through real files (make_golden.py featgen)."""

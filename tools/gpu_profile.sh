@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # STEADY STATE: every pass runs W warm frames from the zero state before the K frames whose launches are summarised (the history
 # ring holds 12 frames; until it has filled the pitch search returns T = 768 and the comb filter reads its largest window)
 W=${PN_PROF_WARMUP:-24}; K=${PN_PROF_STEPS:-5}
-B="python $R/bench.py --no-cpu-baseline --no-parity --no-sustained --no-other-configs --no-distinct $@"
+B="python $R/bench.py --no-cpu-baseline --no-parity --no-sustained --no-other-configs --no-realtime $@"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $B --steps $K --warmup $W > $OUT/stats_bench.json 2> $OUT/stats.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $B --steps $K --warmup $W --no-profile > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $B --steps $K --warmup $W --no-profile > /dev/null 2> $OUT/pmc_write.err
