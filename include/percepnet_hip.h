@@ -210,6 +210,11 @@ long long pn_ctx_debug_copy(pn_ctx *ctx, int which, void *dst, long long max_byt
    launcher for a refused geometry. */
 int pn_debug_check_launch(int kind, int n_panels, int width, int n_out);
 int pn_ctx_debug_inject_launch_failure(pn_ctx *ctx, int enable);
+/* The digest function behind the shared-weights cache key (SHA-256, FIPS 180-4), exposed so that the CPU tests can check it
+   against known answers: a model's packed device copy is shared by every context whose model has the same digest. */
+void pn_debug_sha256(const void *data, size_t len, unsigned char out[32]);
+/* SHA-256 of a model's content (arrays in storage order, then each layer's activation and reset_after as two int32). */
+void pn_model_digest(const pn_model *model, unsigned char out[32]);
 
 /* ---- batched training-feature generator ----------------------------------- */
 /* The reference's `percepNet <speech> <noisy> <count> <output>` binary (train(), denoise.cpp:603-787,

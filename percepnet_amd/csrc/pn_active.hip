@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void pn_inactive_fixup_kernel(PnActiveArgs a) 
     if (a.d_gr) for (int c = tid; c < 68; c += 256) a.d_gr[(size_t)s * 68 + c] = a.save_gr[(size_t)i * 68 + c];
     if (tid == 0) { a.last_period[s] = a.save_period[i]; a.last_gain[s] = a.save_gain[i]; }
   }
+  if (a.restore_only) return;
   // (a) rings: t / tn are the counters of the tick that has just run
   const int t12 = (int)(a.t % 12), t6 = (int)(a.t % 6), n5 = (int)(a.tn % 5), n3 = (int)(a.tn % 3), n2 = (int)(a.tn & 1);
   {   // history: frames t-1 .. t-11 (slots t-1 .. t-11 mod 12) one slot up; slots sit back to back inside the row

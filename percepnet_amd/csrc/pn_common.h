@@ -64,8 +64,7 @@ struct pn_model {
   PnLayerHost L[PN_NLAYERS];
   float *storage;               // one malloc holding every array
   size_t n_floats;
-  uint64_t content_hash;        // of the arrays and the layer descriptors: key of the per-device cache of packed weights
-  uint64_t content_hash2;       // a second, independent hash (FNV-1a over the bytes); a cache hit is also compared byte for byte
+  unsigned char sha256[32];     // SHA-256 of the arrays and the layer descriptors: key of the per-device cache of packed weights
 };
 
 #ifndef PN_NO_HIP

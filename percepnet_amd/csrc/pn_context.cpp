@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
+#include <array>
 #include <map>
 #include <mutex>
 #include <string>
@@ -37,23 +38,15 @@ struct SharedWeights {
   DevLayer L[PN_NLAYERS];
   std::vector<void *> allocs;
   size_t bytes = 0;
-  bool cached = false;             // in g_weights (a copy built after a hash collision is private to its context)
-  std::vector<float> host;         // the model arrays this copy was built from: a cache hit is compared byte for byte
-  PnLayerHost desc[PN_NLAYERS];    // ... and layer descriptor for layer descriptor (activation, reset_after)
 };
-// two independent content hashes + array length, device, nn_mode, narrow layers packed for the n16 kernel.  The hashes are
-// not cryptographic (a PNW1 file can be crafted to collide): the key only FINDS a candidate, the byte comparison decides.
-typedef std::tuple<uint64_t, uint64_t, size_t, int, int, int> WeightsKey;
+// SHA-256 of the model content (pn_model_from_sources: arrays + activations + reset_after), array length, device, nn_mode, narrow
+// layers packed for the n16 kernel.  The digest IS the identity: no host copy of the model is kept and nothing is compared byte for
+// byte on a hit (round 5 kept 32 MB per entry and memcmp'ed it under the build lock).
+typedef std::tuple<std::array<unsigned char, 32>, size_t, int, int, int> WeightsKey;
 static std::mutex g_weights_mu;                              // guards g_weights and every refs counter
 static std::mutex g_weights_build_mu[16];                    // per device (mod 16): uploads and re-packs of DIFFERENT devices run
                                                              // side by side (percepnet_run --devices creates its contexts from one thread per device)
 static std::map<WeightsKey, SharedWeights *> g_weights;
-static bool same_model(const SharedWeights *w, const pn_model *m) {
-  if (w->host.size() != m->n_floats || memcmp(w->host.data(), m->storage, m->n_floats * 4) != 0) return false;
-  for (int li = 0; li < PN_NLAYERS; li++)
-    if (w->desc[li].act != m->L[li].act || w->desc[li].reset_after != m->L[li].reset_after) return false;
-  return true;
-}
 
 struct pn_ctx {
   int device, B, nn_mode;
@@ -224,7 +217,7 @@ extern "C" void pn_ctx_destroy(pn_ctx *c) {
     std::lock_guard<std::mutex> lk(g_weights_mu);
     if (--c->weights->refs == 0) {
       for (void *p : c->weights->allocs) hipFree(p);
-      if (c->weights->cached) g_weights.erase(c->weights_key);
+      g_weights.erase(c->weights_key);
       delete c->weights;
     }
   }
@@ -362,26 +355,24 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   {   // the device copy of the weights: shared with every other context of this model content on this device in this mode
     // narrow layers on the 16x16x4 kernel at small batches in every MFMA mode (in the shadow-operand modes that is fc_rb; fc_gb runs on their own kernels)
     const bool n16 = (nn_mode != PN_NN_STRICT) && (force_n16 >= 0 ? force_n16 != 0 : n16_rows_ok(n_streams));
-    c->weights_key = std::make_tuple(model->content_hash, model->content_hash2, model->n_floats, device, nn_mode, n16 ? 1 : 0);
+    std::array<unsigned char, 32> dig;
+    memcpy(dig.data(), model->sha256, 32);
+    c->weights_key = std::make_tuple(dig, model->n_floats, device, nn_mode, n16 ? 1 : 0);
     std::lock_guard<std::mutex> build_lk(g_weights_build_mu[device & 15]);   // one build per device at a time; the map lock is never held across a build
-    SharedWeights *hit = NULL; bool collision = false;
+    SharedWeights *hit = NULL;
     {
       std::lock_guard<std::mutex> lk(g_weights_mu);
       auto it = g_weights.find(c->weights_key);
-      if (it != g_weights.end()) {
-        if (same_model(it->second, model)) { hit = it->second; hit->refs++; }
-        else collision = true;                           // same key, different bytes: this context gets a private copy
-      }
+      if (it != g_weights.end()) { hit = it->second; hit->refs++; }
     }
     if (hit) { c->weights = hit; c->weights_were_cached = true; }
     else {
       SharedWeights *w = build_weights(c, model, nn_mode, n16);
       if (!w) goto fail;
-      w->host.assign(model->storage, model->storage + model->n_floats);
-      memcpy(w->desc, model->L, sizeof(w->desc));
-      w->refs = 1; w->cached = !collision;
+      w->refs = 1;
       c->weights = w;
-      if (!collision) { std::lock_guard<std::mutex> lk(g_weights_mu); g_weights[c->weights_key] = w; }
+      std::lock_guard<std::mutex> lk(g_weights_mu);
+      g_weights[c->weights_key] = w;
     }
     memcpy(c->L, c->weights->L, sizeof(c->L));
   }
@@ -579,7 +570,7 @@ static int launch_rnn(pn_ctx *c) {
     PnSegs A = seg1(c->feat, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
     if (c->inject_bad_launch && !strict) A.width[0] = 96;   // test hook: three K-tiles, which every MFMA dense launcher refuses
     rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, (int)B, c->small);
-    if (x3) pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp, np); }   // fc runs in fp32 (70 inputs); its output enters the shadow-operand layers
+    if (x3) rc |= pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp, np); }   // fc runs in fp32 (70 inputs); its output enters the shadow-operand layers
   { Scope sc(c, KF_CONV1);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128; A.ld[j] = 128; A.width[j] = 128; }
@@ -904,7 +895,14 @@ static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr,
   a.np = c->c1ringH ? (int)shadow_halfs_per_element(c) : 0;
   a.B = B; a.Bp = (long long)c->Bp; a.t = c->t; a.tn = c->tn;
   pn_launch_inactive_save(c->stream, a, ni);
-  if (process_dev(c, d_in, d_out, d_gr, is_i16)) return -1;
+  if (process_dev(c, d_in, d_out, d_gr, is_i16)) {
+    // a refused launch: the frame did not complete and the counters did not advance, but the front end may already have
+    // written last_period / last_gain and the caller's rows may hold anything — the SKIPPED streams still get their in-place
+    // state and their output rows back, as the header promises (the error message of the refusal is kept)
+    a.restore_only = 1;
+    pn_launch_inactive_fixup(c->stream, a, ni);
+    return -1;
+  }
   pn_launch_inactive_fixup(c->stream, a, ni);           // a.t / a.tn: the counters the frame above ran with
   PN_HIP_CHECK(hipGetLastError());
   return 0;
@@ -1185,9 +1183,10 @@ static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2,
     return to_device ? hipMemcpy2DAsync(dev, dpitch * 4, host, hpitch * 4, width * 4, B, kind, c->stream)
                      : hipMemcpy2DAsync(host, hpitch * 4, dev, dpitch * 4, width * 4, B, kind, c->stream);
   };
+  int split_rc = 0;
   auto resplit = [&](float *dev, int width) {
-    if (x3) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 2);
-    if (f16) pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 1);
+    if (x3) split_rc |= pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 2);
+    if (f16) split_rc |= pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 1);
   };
   if (conv1) for (int j = 0; j < 4; j++) {
     float *d = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128;
@@ -1201,7 +1200,7 @@ static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2,
     if (gru[i]) { float *d = c->gru[i] + (size_t)(t & 1) * Bp * 512; PN_HIP_CHECK(cp2d(gru[i], 512, d, 512, 512)); resplit(d, 512); }
   if (rb) { float *d = c->rb + (size_t)(t & 1) * Bp * 128; PN_HIP_CHECK(cp2d(rb, 128, d, 128, 128)); resplit(d, 128); }
   PN_HIP_CHECK(hipStreamSynchronize(c->stream));
-  return 0;
+  return split_rc ? -1 : 0;                  // a refused shadow-operand split (pn_launch_split_x3) fails the call, like any refused launch
 }
 extern "C" int pn_ctx_set_rnn_state_host(pn_ctx *c, const float *conv1, const float *conv2, const float *gru1, const float *gru2,
                                          const float *gru3, const float *gru_gb, const float *gru_rb) {

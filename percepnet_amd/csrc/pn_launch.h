@@ -46,6 +46,8 @@ struct PnActiveArgs {
   float *hist; float2 *yring; float *eyring, *c1ring, *c2ring, *gru[4], *rb;
   uint4 *c1ringH, *c2ringH, *gruH[4], *rbH; int np;  // operand shadows (np = 0: none)
   long long B, Bp, t, tn;                            // t / tn: the counters of the tick the fix-up follows
+  int restore_only;                                  // the frame FAILED (a refused launch): put the in-place state and the caller's rows of the
+                                                     // skipped streams back, shift nothing (the context's counters did not advance)
 };
 void pn_launch_inactive_save(hipStream_t st, const PnActiveArgs &a, int n);
 int pn_launch_spin(hipStream_t st, long long ticks);     // one wave asleep for `ticks` of the 100 MHz wall clock (queue probe)
@@ -74,7 +76,7 @@ int pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const 
 int pn_x3_rg_for(int n_rows);
 int pn_x3_sat_set(int enable);          // debug counter of operand values clamped to +-65504 (current device): reset + switch
 long long pn_x3_sat_read();             // ... and its value, or -1
-void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np);
+int pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np);
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);

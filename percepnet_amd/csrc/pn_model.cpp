@@ -41,6 +41,64 @@ static int check_geometry(int li, int kind, int nin, int nn, int ks) {
 
 
 
+// ---- SHA-256 (FIPS 180-4) of a model's content: the key of the per-device cache of packed weights (pn_context.cpp).  A strong
+// digest, computed ONCE per model, instead of two 64-bit hashes plus a retained 32 MB host copy that every cache hit was compared
+// against byte for byte under the build lock (advisor, round 5): a PNW1 file cannot be crafted to share another model's entry.
+namespace {
+struct Sha256 {
+  uint32_t h[8]; uint64_t n; unsigned char buf[64]; size_t fill;
+  Sha256() : n(0), fill(0) {
+    static const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    memcpy(h, iv, sizeof(h));
+  }
+  static uint32_t ror(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+  void block(const unsigned char *p) {
+    static const uint32_t K[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+      0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+      0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+      0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+      0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+      0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const void *data, size_t len) {
+    const unsigned char *p = (const unsigned char *)data;
+    n += len;
+    if (fill) {
+      const size_t take = len < 64 - fill ? len : 64 - fill;
+      memcpy(buf + fill, p, take); fill += take; p += take; len -= take;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+    for (; len >= 64; p += 64, len -= 64) block(p);
+    if (len) { memcpy(buf, p, len); fill = len; }
+  }
+  void finish(unsigned char out[32]) {
+    const uint64_t bits = n * 8;
+    const unsigned char one = 0x80, zero = 0;
+    update(&one, 1);
+    while (fill != 56) update(&zero, 1);
+    unsigned char lenb[8];
+    for (int i = 0; i < 8; i++) lenb[i] = (unsigned char)(bits >> (56 - 8 * i));
+    update(lenb, 8);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (unsigned char)(h[i] >> 24); out[4 * i + 1] = (unsigned char)(h[i] >> 16); out[4 * i + 2] = (unsigned char)(h[i] >> 8); out[4 * i + 3] = (unsigned char)h[i]; }
+  }
+};
+}  // namespace
+extern "C" void pn_debug_sha256(const void *data, size_t len, unsigned char out[32]) { Sha256 s; s.update(data, len); s.finish(out); }
+
 pn_model *pn_model_from_sources(const PnLayerSrc *src) {
   size_t total = 0;
   for (int li = 0; li < PN_NLAYERS; li++) {
@@ -64,18 +122,14 @@ pn_model *pn_model_from_sources(const PnLayerSrc *src) {
     memcpy(p, src[li].w, nw * 4); L.w = p; p += nw;
     if (nr) { memcpy(p, src[li].rw, nr * 4); L.rw = p; p += nr; } else L.rw = NULL;
   }
-  // content hash (64-bit multiply-xorshift over 8-byte words; the arrays are 4-byte floats, n_floats is even or the last
-  // word is taken alone): two models with the same weights and activations share one packed copy per device and mode
-  uint64_t h = 0x9e3779b97f4a7c15ull;
-  auto mix = [&](uint64_t v) { h ^= v; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; };
-  for (size_t i = 0; i + 1 < total; i += 2) { uint64_t v; memcpy(&v, m->storage + i, 8); mix(v); }
-  if (total & 1) { uint32_t v; memcpy(&v, m->storage + total - 1, 4); mix(v); }
-  for (int li = 0; li < PN_NLAYERS; li++) mix(((uint64_t)(uint32_t)m->L[li].act << 32) | (uint32_t)m->L[li].reset_after);
-  m->content_hash = h;
-  uint64_t f = 0xcbf29ce484222325ull;                  // FNV-1a, byte-wise: shares no structure with the word-wise mix above
-  const unsigned char *bytes = (const unsigned char *)m->storage;
-  for (size_t i = 0; i < total * 4; i++) { f ^= bytes[i]; f *= 0x100000001b3ull; }
-  m->content_hash2 = f;
+  // content digest: every array byte in storage order, then every layer's (activation, reset_after) — what the packed device
+  // copy depends on besides the fixed topology
+  {
+    Sha256 sh;
+    sh.update(m->storage, total * sizeof(float));
+    for (int li = 0; li < PN_NLAYERS; li++) { const int32_t d[2] = {m->L[li].act, m->L[li].reset_after}; sh.update(d, sizeof(d)); }
+    sh.finish(m->sha256);
+  }
   return m;
 }
 
@@ -142,5 +196,6 @@ extern "C" pn_model *pn_model_from_file(FILE *f) {
   return pn_model_from_blob(buf.data(), buf.size());
 }
 
+extern "C" void pn_model_digest(const pn_model *m, unsigned char out[32]) { if (m && out) memcpy(out, m->sha256, 32); }
 extern "C" void pn_model_free(pn_model *m) { if (m) { free(m->storage); free(m); } }
 

@@ -937,7 +937,12 @@ int pn_launch_gru_x3(hipStream_t st, const PnSegs &X, const float *h_old, const 
   return 0;
 }
 
-void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np) {
+// refuses (-1, pn_set_error, nothing launched) a width that is not whole groups of 8 columns or a plane count other than 1 / 2
+int pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np) {
+  if (width < 8 || (width & 7) || ld < width || n_rows_padded < 1 || (np != 1 && np != 2) || !src || !S) {
+    pn_set_error("pn_launch_split_x3: width %d (whole groups of 8), row stride %d, %d rows, %d plane(s)", width, ld, n_rows_padded, np);
+    return -1;
+  }
   const size_t n = (size_t)n_rows_padded * (width >> 3);
   if (np == 2)
     hipLaunchKernelGGL(pn_split_x3_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ld, width, (uint4 *)S,
@@ -945,4 +950,5 @@ void pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, voi
   else
     hipLaunchKernelGGL(pn_split_x3_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ld, width, (uint4 *)S,
                        n_rows_padded);
+  return 0;
 }

@@ -8,17 +8,24 @@
 //
 // One DenoiseState = a batch-of-one context.  That is correct but launch-bound (15 kernel
 // launches and two PCIe hops per 10 ms frame); throughput lives in the batched pn_* API.  N handles of one model share
-// ONE DEVICE copy of the weights (pn_context.cpp: SharedWeights, found by content); each handle still owns its host-side
-// pn_model (a 32 MB copy of the arrays it was given, hashed once): the RNNModel a caller passes is borrowed memory that
-// may be changed or freed between two rnnoise_init calls, so nothing host-side is keyed on its address here.
+// ONE DEVICE copy of the weights (pn_context.cpp: SharedWeights, found by the model's SHA-256).  Host side (round 6): a handle
+// keeps NO copy of the model.  The host pn_model a context is created from comes from
+//   * the OwnedModel behind an RNNModel that rnnoise_model_from_file returned (the arrays ARE that pn_model's: zero copies);
+//   * one process-wide pn_model of the link-time percepnet_model_orig (immutable .rodata) / of the PERCEPNET_MODEL file
+//     (keyed by path, size and mtime), built on first use and kept;
+//   * a temporary built from a caller's own RNNModel — borrowed, mutable memory, so nothing is keyed on its address — and freed
+//     as soon as the context exists (a context retains no host pointer).
+// Round 5 copied 32 MB and hashed them twice for every rnnoise_init and kept the copy for the life of the handle.
 #include "pn_common.h"
 #include "../../include/percepnet_hip.h"
 // the reference's own (C++-mangled) entry points: exported like the C-ABI (the library is built with -fvisibility=hidden)
 #define PN_REF_EXPORT __attribute__((visibility("default")))
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <map>
 #include <mutex>
+#include <string>
 
 // link-time model of the reference (denoise.cpp:49-51): generated nnet_data.cpp defines it.
 // Weak: a caller may instead pass a model explicitly or set PERCEPNET_MODEL=<file.pnw>.
@@ -27,7 +34,7 @@ extern const RNNModel percepnet_model_orig __attribute__((weak));
 struct DenoiseState {
   uint32_t magic;
   pn_ctx *ctx;
-  pn_model *model;
+  pn_model *unused_model;        // (round 5 kept a private 32 MB host copy here)
   float gr[68];
   int failed;
 };
@@ -49,26 +56,68 @@ static int env_mode() {
   return (x && atoi(x)) ? PN_NN_MFMA_X3 : PN_NN_MFMA;
 }
 
+// ---- host models shared between handles ------------------------------------------------------------------------------
+struct OwnedModel;
+static pn_model *owned_model_of(const RNNModel *m);          // the pn_model behind an RNNModel of rnnoise_model_from_file, or NULL
+static std::mutex g_host_mu;                                 // guards the two process-wide models and the live-state registry
+static pn_model *g_linked_model = NULL;                      // of percepnet_model_orig
+static pn_model *g_env_model = NULL; static std::string g_env_key;   // of the PERCEPNET_MODEL file: path | size | mtime
+static std::map<const DenoiseState *, pn_ctx *> g_live;      // states that own a context, and which (the registry, not the state's
+                                                             // memory, is the authority: the memory may be fresh from malloc)
+
+// -> the host model to create a context from; *temp = it is the caller's to free once the context exists
+static pn_model *host_model_for(RNNModel *model, bool *temp) {
+  *temp = false;
+  if (model) {
+    if (pn_model *pm = owned_model_of(model)) return pm;
+    if (&percepnet_model_orig && model == &percepnet_model_orig) {
+      if (!g_linked_model) g_linked_model = pn_model_from_rnnmodel(model);
+      return g_linked_model;
+    }
+    *temp = true;
+    return pn_model_from_rnnmodel(model);
+  }
+  if (&percepnet_model_orig) {
+    if (!g_linked_model) g_linked_model = pn_model_from_rnnmodel(&percepnet_model_orig);
+    return g_linked_model;
+  }
+  if (const char *path = getenv("PERCEPNET_MODEL")) {
+    struct stat sb;
+    if (stat(path, &sb) != 0) { fprintf(stderr, "percepnet_hip: rnnoise_init: cannot open PERCEPNET_MODEL=%s\n", path); return NULL; }
+    const std::string key = std::string(path) + "|" + std::to_string((long long)sb.st_size) + "|" + std::to_string((long long)sb.st_mtime);
+    if (g_env_model && key == g_env_key) return g_env_model;
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "percepnet_hip: rnnoise_init: cannot open PERCEPNET_MODEL=%s\n", path); return NULL; }
+    pn_model *pm = pn_model_from_file(f);
+    fclose(f);
+    if (pm) { g_env_model = pm; g_env_key = key; }      // the previous file's model (if any) may still be creating a context on another
+    return pm;                                            // thread only under g_host_mu, which we hold: safe to replace; it is leaked by design
+  }                                                       // (one per CHANGED file per process) rather than freed under a reader
+  return NULL;
+}
+
 PN_REF_EXPORT int rnnoise_init(DenoiseState *st, RNNModel *model) {
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  // (re-)initialising memory the registry knows as a live state — rnnoise_init twice, or a state that was free()d without
+  // rnnoise_destroy and whose address came back from malloc: the reference leaks nothing in either case (its state is plain
+  // memory); a context is device memory and a stream, so the old one is released first
+  { auto it = g_live.find(st); if (it != g_live.end()) { pn_ctx_destroy(it->second); g_live.erase(it); } }
   memset(st, 0, sizeof(*st));
   st->magic = DS_MAGIC;
-  const RNNModel *m = model ? model : (&percepnet_model_orig ? &percepnet_model_orig : NULL);
-  if (m) st->model = pn_model_from_rnnmodel(m);
-  else if (const char *path = getenv("PERCEPNET_MODEL")) {
-    FILE *f = fopen(path, "rb");
-    if (f) { st->model = pn_model_from_file(f); fclose(f); }
-    else fprintf(stderr, "percepnet_hip: rnnoise_init: cannot open PERCEPNET_MODEL=%s\n", path);
-  }
-  if (!st->model) {
+  bool temp = false;
+  pn_model *pm = host_model_for(model, &temp);
+  if (!pm) {
     fprintf(stderr, "percepnet_hip: rnnoise_init: no model (pass an RNNModel, link a generated nnet_data.cpp defining "
                     "percepnet_model_orig, or set PERCEPNET_MODEL=<file.pnw>)%s%s: the state is INERT, "
                     "rnnoise_process_frame will output silence\n", pn_last_error()[0] ? ": " : "", pn_last_error());
     return 0;
   }
-  st->ctx = pn_ctx_create(st->model, env_device(), 1, env_mode(), NULL);
+  st->ctx = pn_ctx_create(pm, env_device(), 1, env_mode(), NULL);
+  if (temp) pn_model_free(pm);                            // a context keeps no host pointer into the model it was created from
   if (!st->ctx)
     fprintf(stderr, "percepnet_hip: rnnoise_init: %s: the state is INERT, rnnoise_process_frame will output silence "
                     "(this library has no CPU fallback)\n", pn_last_error());
+  else g_live[st] = st->ctx;
   return 0;
 }
 
@@ -80,7 +129,11 @@ PN_REF_EXPORT DenoiseState *rnnoise_create(RNNModel *model) {
 
 PN_REF_EXPORT void rnnoise_destroy(DenoiseState *st) {
   if (!st) return;
-  if (st->magic == DS_MAGIC) { pn_ctx_destroy(st->ctx); pn_model_free(st->model); }
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_live.find(st);
+    if (it != g_live.end()) { pn_ctx_destroy(it->second); g_live.erase(it); }
+  }
   free(st);
 }
 
@@ -156,6 +209,11 @@ PN_REF_EXPORT void compute_rnn(RNNState *rnn, float *gains, float *strengths, co
 struct OwnedModel { RNNModel m; DenseLayer d[3]; Conv1DLayer c[2]; GRULayer g[5]; pn_model *pm; };
 static std::mutex g_owned_mu;
 static std::map<const RNNModel *, OwnedModel *> g_owned;
+static pn_model *owned_model_of(const RNNModel *m) {
+  std::lock_guard<std::mutex> lk(g_owned_mu);
+  auto it = g_owned.find(m);
+  return it == g_owned.end() ? NULL : it->second->pm;
+}
 
 PN_REF_EXPORT RNNModel *rnnoise_model_from_file(FILE *f) {
   pn_model *pm = pn_model_from_file(f);

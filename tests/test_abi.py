@@ -55,6 +55,43 @@ def test_model_parsing_and_error_paths_without_gpu(lib, blob):
     m.close()
 
 
+def test_model_digest_is_sha256_of_the_content(lib, blob):
+    """The shared-weights cache (pn_context.cpp) is keyed by SHA-256 of the model content — a strong digest instead of round 5's two
+    64-bit hashes + retained host copy.  Known answers for the hash itself, and the model digest recomputed with hashlib from the
+    PNW1 container: array bytes in layer order, then (activation, reset_after) of every layer."""
+    import hashlib
+    import struct
+    from percepnet_amd import weights
+    lib.pn_debug_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    lib.pn_debug_sha256.restype = None
+    for msg in (b"", b"abc", b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq", b"a" * 1000003, bytes(range(256)) * 257):
+        out = ctypes.create_string_buffer(32)
+        lib.pn_debug_sha256(msg, len(msg), out)
+        assert out.raw == hashlib.sha256(msg).digest(), len(msg)
+    L = api.load_library()
+    L.pn_model_digest.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.pn_model_digest.restype = None
+    m = api.Model(blob)
+    out = ctypes.create_string_buffer(32)
+    L.pn_model_digest(m.h, out)
+    h = hashlib.sha256()
+    off, tail = 8, b""
+    for _ in range(struct.unpack_from("<I", blob, 4)[0]):
+        kind, nin, nn, ks, act, ra = struct.unpack_from("<6I", blob, off); off += 24
+        n = (6 * nn if kind == 2 else nn) + nin * ks * nn * (3 if kind == 2 else 1) + (nn * 3 * nn if kind == 2 else 0)
+        h.update(blob[off:off + 4 * n]); off += 4 * n
+        tail += struct.pack("<2i", act, ra)
+    h.update(tail)
+    assert off == len(blob) and out.raw == h.digest()
+    # one flipped weight bit, or one changed activation, is another model
+    for patch_at, val in ((len(blob) - 5, blob[len(blob) - 5] ^ 1), (8 + 16, (blob[8 + 16] + 1) % 4)):
+        b2 = bytearray(blob); b2[patch_at] = val
+        m2 = api.Model(bytes(b2)); o2 = ctypes.create_string_buffer(32)
+        L.pn_model_digest(m2.h, o2); m2.close()
+        assert o2.raw != out.raw
+    m.close()
+
+
 def test_header_is_plain_c_and_a_c_caller_links(lib, blob, tmp_path):
     """gcc -std=c99 compiles a caller against include/percepnet_hip.h and links libpercepnet_hip.so; without a GPU it
     must report the missing device through pn_last_error() and exit cleanly (never fall back to a CPU path)."""

@@ -257,6 +257,42 @@ def test_a_refused_launch_fails_the_frame(model, mode):
     ctx.close(); good.close()
 
 
+def test_a_failed_active_frame_leaves_the_skipped_streams_alone(model):
+    """Advisor (round 5): when the frame inside pn_process_*_active is refused, the streams the call SKIPS must still get their
+    output rows and in-place state back (the header promises those rows are untouched).  After the failure the hook is switched
+    off and the same tick is run again: every stream — the skipped ones included, which skipped twice — continues bit-identically
+    to a context that never saw the failure."""
+    import torch
+    B, T = 64, 8
+    pcm = synth.synth_batch(B, T)
+    dev = torch.device("cuda:0")
+    act = [s for s in range(B) if s % 5]
+    skipped = [s for s in range(B) if s % 5 == 0]
+    ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+    good = api.Context(model, B, nn_mode=api.NN_MFMA)
+    o1 = torch.zeros((B, 480), dtype=torch.int16, device=dev); o2 = torch.zeros_like(o1)
+    g1 = torch.zeros((B, 68), dtype=torch.float32, device=dev); g2 = torch.zeros_like(g1)
+    fr = [torch.from_numpy(np.ascontiguousarray(pcm[:, t * 480:(t + 1) * 480])).to(dev) for t in range(T)]
+    torch.cuda.synchronize()
+    for t in range(3):
+        ctx.process_i16_dev(fr[t].data_ptr(), o1.data_ptr(), g1.data_ptr()); good.process_i16_dev(fr[t].data_ptr(), o2.data_ptr(), g2.data_ptr())
+    ctx.synchronize(); good.synchronize()
+    before_o, before_g = o1.clone(), g1.clone()
+    ctx.debug_inject_launch_failure(True)
+    with pytest.raises(api.PercepNetError, match="pn_launch_dense"):
+        ctx.process_i16_active_dev(fr[3].data_ptr(), o1.data_ptr(), g1.data_ptr(), act)
+    ctx.synchronize()
+    assert torch.equal(o1[skipped], before_o[skipped]) and torch.equal(g1[skipped], before_g[skipped])
+    ctx.debug_inject_launch_failure(False)
+    for t in range(3, T):
+        ids = act if t == 3 else list(range(B))
+        ctx.process_i16_active_dev(fr[t].data_ptr(), o1.data_ptr(), g1.data_ptr(), ids)
+        good.process_i16_active_dev(fr[t].data_ptr(), o2.data_ptr(), g2.data_ptr(), ids)
+        ctx.synchronize(); good.synchronize()
+        assert torch.equal(o1, o2) and torch.equal(g1, g2), t
+    ctx.close(); good.close()
+
+
 def test_active_set_on_the_pipelined_host_path(model):
     """pn_submit_host_i16_active = pn_process_i16_active behind the pipelined copy-in / compute / copy-out path: the rows of
     the streams that take part equal the device-pointer path's bit for bit, also after a stream has skipped ticks; a refused

@@ -81,6 +81,29 @@ def test_hip_path_straight_against_the_compiled_reference(model, blob):
     assert np.abs(ro.astype(np.int32)).max() > 1000 and (ro[2] != 0).any()       # the loud stream is not silence at the output
 
 
+def test_tail_rows_on_the_small_kernels_bit_identical(model, oracle, monkeypatch):
+    """Round-5 verdict item 3: a batch whose 128-row tiles do not fill a whole number of rounds of 512 co-resident blocks used to pay
+    a full round for its last rows.  The rows past the last whole round now run on the small-batch kernel family (pn_nn.hip
+    pn_body_rows).  4096 + 300 streams = one whole round of the 512-wide layers + a 300-row tail (and, for the 128-wide GRU, no
+    tail at all): bit-identical to the same batch with the split switched off (PERCEPNET_TAIL_ROWS=0), every stream, PCM and g,r;
+    and the tail rows still follow the oracle."""
+    B, T = 4096 + 300, 6
+    pool = synth.synth_batch(64, T)
+    pcm = pool[np.arange(B) % 64].copy()
+    pcm[4096:] = np.roll(pcm[4096:], 11, axis=1)                    # the tail rows are not copies of body rows
+    outs = []
+    for tail in ("0", "1536"):
+        monkeypatch.setenv("PERCEPNET_TAIL_ROWS", tail)
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+        outs.append(ctx.run_pcm(pcm))
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    for s in (4096, 4200, B - 1):
+        ro, rg = oracle.run_pcm(pcm[s])
+        assert np.abs(outs[1][0][s].astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+        assert np.abs(outs[1][1][s] - rg).max() <= GR_TOL
+
+
 def test_postfilter_option(model, oracle):
     """the optional envelope post-filter (reference post_filtering, denoise.cpp:216-250) between
     the g/r tap and pitch_filter.  The network and its tap are untouched (bit-identical, STRICT); the PCM follows the
