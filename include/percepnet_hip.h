@@ -147,6 +147,10 @@ int pn_process_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float 
 int pn_submit_host_f32(pn_ctx *ctx, const float *h_in, float *h_out, float *h_gr);
 int pn_submit_host_i16(pn_ctx *ctx, const int16_t *h_in, int16_t *h_out, float *h_gr);
 int pn_host_wait(pn_ctx *ctx);               /* every submitted frame delivered */
+/* Builds the three-stream pipeline NOW instead of inside the first pn_submit_host_* call: the copy streams are probed against
+   the context's stream (a 1 ms sleeper kernel on it, up to 6 attempts x 3 pairings: tens of milliseconds; not legal while that
+   stream is being captured).  A caller on a real-time clock calls this once before its first frame arrives. */
+int pn_host_pipeline_prepare(pn_ctx *ctx);
 /* Non-blocking: how many submitted frames have been DELIVERED (output copy complete) so far; -1 on error.  For callers on a
    real-time clock that timestamp each frame's delivery between arrivals (reference contract: src/main.cpp:30-39). */
 int64_t pn_host_frames_delivered(pn_ctx *ctx);

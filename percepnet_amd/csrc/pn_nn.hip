@@ -559,23 +559,6 @@ int pn_small_gru_rows() {
   const int d = pn_small_rows();
   return d < 1536 ? d : 1536;
 }
-// The batch kernels above run in ROUNDS of 512 co-resident blocks (two 256-thread blocks on each of the 256 CUs); a tile takes the
-// same ~98 us whether its round is full or not, so a batch whose tile count is not a whole number of rounds used to pay a full round
-// for its last few hundred rows: 65 536 streams = 16 rounds of the 512-wide layers, 66 048 = 17 (+0.45 ms per frame: DESIGN.md 8,
-// round-5 verdict item 3 — the reference has no such step, its cost is per stream: nnet.cpp:120-180).  The rows past the last WHOLE
-// round now run on the small-batch kernel family (pn_nn_small.hip: one 32 x 32 tile per wave, 12-16x more blocks, the same chains
-// and MFMAs — results do not depend on the family), whose cost grows with the row count; above PERCEPNET_TAIL_ROWS (default 1536
-// rows: the measured crossover against one more batch round) the tail stays on the batch kernels.  -> rows for the batch kernels.
-int pn_tail_rows_max() {                     // read at every launch (tests switch it between two contexts of one process)
-  const char *e = getenv("PERCEPNET_TAIL_ROWS");
-  return e ? atoi(e) : 1536;
-}
-static int pn_body_rows(int n_rows, int n_ctiles) {
-  const int per_round = (512 / n_ctiles) * BM;                // rows one round of 512 blocks covers (512-wide layers: 32 M tiles = 4096 rows)
-  if (per_round <= 0 || n_rows <= per_round) return n_rows;
-  const int body = n_rows / per_round * per_round, tail = n_rows - body;
-  return (tail > 0 && tail <= pn_tail_rows_max()) ? body : n_rows;
-}
 int pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, const float *bias, int N, int act,
                           const float *tansig, float *out, int ldo, int n_rows, int ct_padded);
 int pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
@@ -596,20 +579,14 @@ int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W,
   // context accepts, pn_context.cpp:check_geometry) has an even number of them (4, 20, 48, 80, 4)
   if (pn_check_dense_geometry("pn_launch_dense", A.n, A.width, 0)) return -1;
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
-  const int body = pn_body_rows(n_rows, n_cblocks);         // whole rounds of co-resident blocks; the rest: see pn_body_rows
-  if (body < n_rows) {
-    PnSegs At = A;
-    for (int j = 0; j < A.n; j++) At.p[j] = A.p[j] + (size_t)body * A.ld[j];
-    if (pn_launch_dense_small(st, At, Wp, bias, N, act, tansig, out + (size_t)body * ldo, ldo, n_rows - body, pn_ct_padded(N, NT))) return -1;
-  }
-  const int n_mtiles = (body + BM - 1) / BM;
+  const int n_mtiles = (n_rows + BM - 1) / BM;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
   if (NT == 4)
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                       tansig, out, ldo, body, n_mtiles, n_cblocks);
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   else
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<2>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
-                       tansig, out, ldo, body, n_mtiles, n_cblocks);
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   return 0;
 }
 
@@ -626,15 +603,9 @@ int pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_ol
   }
   const int tps = (X.width[0] + 31) / 32, KTx = tps * X.n;   // equal-width panels
   const int NTn = N / 32;
-  const int body = pn_body_rows(n_rows, NTn);
-  if (body < n_rows) {                                       // the tail rows first: the small blocks fill the chip while it is otherwise idle
-    PnSegs Xt = X;
-    for (int j = 0; j < X.n; j++) Xt.p[j] = X.p[j] + (size_t)body * X.ld[j];
-    if (pn_launch_gru_small(st, Xt, h_old + (size_t)body * N, Wp, Up, b, N, act, tansig, h_new + (size_t)body * N, n_rows - body)) return -1;
-  }
-  const int n_mtiles = (body + BM - 1) / BM;
+  const int n_mtiles = (n_rows + BM - 1) / BM;
   const int grid = 8 * ((n_mtiles + 7) / 8) * NTn;
   hipLaunchKernelGGL(pn_gru_mfma_p_kernel, dim3(grid), dim3(NN_THREADS), 0, st, X, h_old, Wp, Up, b, N, KTx, tps, act,
-                       tansig, h_new, body, n_mtiles);
+                       tansig, h_new, n_rows, n_mtiles);
   return 0;
 }

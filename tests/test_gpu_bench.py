@@ -91,9 +91,11 @@ def test_paced_real_time_run_through_the_pipelined_host_path():
     # capacity is back on its clock within a few frames and misses nothing after that
     d = bench.paced_realtime(api, synth, model, 0, 4096, api.NN_MFMA, seconds=0.8, stall=(10, 40.0))
     other.close()
-    assert d["recovery"]["recovered"] is True and 1 <= d["recovery"]["frames_to_recover"] <= 12 and d["met_contract"] is True
-    assert d["recovery"]["clean_frames_after_recovery"] >= 20 and 0 < d["recovery"]["delivery_p99_ms_after_recovery"] <= 20.0
-    assert d["recovery"]["frames_to_recover_submit_clock"] <= d["recovery"]["frames_to_recover"]
+    rec = d["recovery"]
+    assert rec["recovered"] is True and d["met_contract"] is True, rec
+    assert 1 <= rec["frames_to_recover_submit_clock"] <= 12, rec           # the submit clock: four frames arrived late, back within a few
+    assert rec["frames_to_recover_submit_clock"] <= rec["frames_to_recover"] <= 50, rec      # ... the last disturbed frame (deliveries included)
+    assert rec["clean_frames_after_recovery"] >= 20 and 0 < rec["delivery_p99_ms_after_recovery"] <= 20.0, rec
     assert d["deadline_misses"] >= 1                        # the stall itself is a missed deadline: it is visible, not hidden
     # the copy streams: default priority and probed ("n"), or the priority fallback ("h" / "l"); back to back the pipeline runs well
     # inside a period at this size

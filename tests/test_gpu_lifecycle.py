@@ -101,6 +101,8 @@ def test_contexts_of_one_model_share_the_device_weights(blob):
     """The reference binds every state to one static model (zero copies).  Here the first context of a (model content,
     device, mode) uploads and re-packs the 32 MB once; every later one — also through a second pn_model handle holding
     the same arrays — points at that copy: its footprint excludes the weights and it is created faster."""
+    # a model content no other test uses (one weight bit flipped): a context another test left open cannot hold its copies
+    blob = bytes(blob[:-4]) + bytes([blob[-4] ^ 1]) + bytes(blob[-3:])
     m1, m2 = api.Model(blob), api.Model(blob)
     t0 = time.perf_counter(); c1 = api.Context(m1, 64); t1 = time.perf_counter()
     c2 = api.Context(m2, 64); t2 = time.perf_counter()

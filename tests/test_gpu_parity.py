@@ -81,24 +81,30 @@ def test_hip_path_straight_against_the_compiled_reference(model, blob):
     assert np.abs(ro.astype(np.int32)).max() > 1000 and (ro[2] != 0).any()       # the loud stream is not silence at the output
 
 
-def test_tail_rows_on_the_small_kernels_bit_identical(model, oracle, monkeypatch):
-    """Round-5 verdict item 3: a batch whose 128-row tiles do not fill a whole number of rounds of 512 co-resident blocks used to pay
-    a full round for its last rows.  The rows past the last whole round now run on the small-batch kernel family (pn_nn.hip
-    pn_body_rows).  4096 + 300 streams = one whole round of the 512-wide layers + a 300-row tail (and, for the 128-wide GRU, no
-    tail at all): bit-identical to the same batch with the split switched off (PERCEPNET_TAIL_ROWS=0), every stream, PCM and g,r;
-    and the tail rows still follow the oracle."""
-    B, T = 4096 + 300, 6
+def test_row_range_chains_bit_identical(model, oracle, monkeypatch):
+    """Round-5 verdict item 3: on one in-order stream every layer of the batch GEMMs pays whole rounds of 512 co-resident blocks
+    (65 536 streams = 16 rounds, 66 048 = 17).  Large fp32 contexts now run the network as row-range chains on streams of their own
+    (pn_context.cpp launch_rnn; default 2 chains above 16 384 streams).  8192 + 300 streams, forced to 1, 2 and 3 chains (ragged
+    last range: 8492 = 4352 + 4140 = 2944 + 2944 + 2604 rows): bit-identical PCM and g,r for every stream, also through the
+    network-only entry point, and the last rows still follow the oracle."""
+    B, T = 8192 + 300, 5
     pool = synth.synth_batch(64, T)
     pcm = pool[np.arange(B) % 64].copy()
-    pcm[4096:] = np.roll(pcm[4096:], 11, axis=1)                    # the tail rows are not copies of body rows
+    pcm[8192:] = np.roll(pcm[8192:], 11, axis=1)                    # the last rows are not copies of earlier rows
+    feat = np.random.default_rng(3).standard_normal((B, 70)).astype(np.float32)
     outs = []
-    for tail in ("0", "1536"):
-        monkeypatch.setenv("PERCEPNET_TAIL_ROWS", tail)
+    for chains in ("1", "2", "3"):
+        monkeypatch.setenv("PN_NN_CHAINS", chains)
         ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
-        outs.append(ctx.run_pcm(pcm))
+        want = chains if chains != "3" else "2"                     # three chains of 2831 rows would be the small-batch regime: capped
+        assert ctx.describe()["nn_chains"].split(":")[0] == want, ctx.describe()
+        o, g = ctx.run_pcm(pcm)
+        outs.append((o, g, ctx.compute_rnn(feat)))
         ctx.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
-    for s in (4096, 4200, B - 1):
+    for o, g, r in outs[1:]:
+        assert np.array_equal(outs[0][0], o) and np.array_equal(outs[0][1].view(np.uint32), g.view(np.uint32))
+        assert np.array_equal(outs[0][2].view(np.uint32), r.view(np.uint32))
+    for s in (4351, 4352, 8192, B - 1):
         ro, rg = oracle.run_pcm(pcm[s])
         assert np.abs(outs[1][0][s].astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
         assert np.abs(outs[1][1][s] - rg).max() <= GR_TOL
