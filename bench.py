@@ -217,27 +217,42 @@ def measure_parity(ctx, frames, pool_pcm, out, torch):
 
 
 def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
-    """The roofline object of the dominant kernel (the 512->512 GRU step, 4 launches per frame) from HIP-event kernel
-    times `kt` of a context described by `desc` (Context.describe())."""
+    """The roofline object of the dominant kernel (the 512->512 GRU step, 4 layers per frame) from HIP-event kernel
+    times `kt` of a context described by `desc` (Context.describe()).
+    Row-range chains (round 6; desc["nn_chains"] = "2:n"): a layer step over the batch is N launches of the kernel, one per chain
+    on its own stream, each over 1/N of the rows, and the N launches of a layer overlap in time — each is bracketed by HIP events on
+    the stream it is launched on and `avg_launch_ms` is the mean over ALL of them.  One launch alone does not have the chip; the chip
+    does `concurrent_launches` of them in that time.  So `achieved` = concurrent_launches x flop_per_launch / avg_launch_ms (the
+    chip's rate while this kernel runs), with the per-launch figures beside it; `whole_pipeline_tflops` — from the wall clock of
+    the timed region alone — is the independent check that the chip-level rate is not double counted."""
     ms, n = kt.get("gru512", (0.0, 0))
     if not n:
         return None
     avg_s = ms / n * 1e-3
-    flops = B * GRU512_FLOP_PER_STREAM_FRAME
+    chains = max(1, int(str(desc.get("nn_chains", "1")).split(":")[0]))
+    rows = B / chains                                     # rows per launch (the chains are equal to within one 128-row tile)
+    flops = rows * GRU512_FLOP_PER_STREAM_FRAME
     x3 = desc.get("nn") == "mfma_x3"
     # the fp16-operand mode runs the hi-plane-only instantiation of the split-precision kernels (pn_nn_x3.hip)
     kname = "pn_gru_x3_kernel" if (x3 or fp16) else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel")
     traffic, traffic_src = pmc_traffic_bytes(B, kname[:11], traffic_tag)
-    ach = flops / avg_s / 1e12
+    ach = chains * flops / avg_s / 1e12
     # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md).  Split precision: `achieved` stays the ALGORITHMIC rate (2 M N K per
     # launch); every product costs three fp16 MFMAs, so the bound is a third of the dense fp16 peak
     peak = round(2500.0 / 3, 1) if x3 else (2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS)
-    r = {"kernel": kname + ("<rows/32, planes=1>" if fp16 else ("<rows/32, planes=2>" if x3 else "")) + " (512->512 reset-after GRU step, 4 launches per frame)",
+    alg_launch = int(3 * rows * 512 * (2 if fp16 else 4) + (rows * 512 * 4 if (fp16 or x3) else 0) + 2 * 512 * 1536 * (2 if fp16 else 4))
+    r = {"kernel": kname + ("<rows/32, planes=1>" if fp16 else ("<rows/32, planes=2>" if x3 else "")) +
+                   f" (512->512 reset-after GRU step, 4 layers per frame x {chains} launch(es) per layer)",
          "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-         "frac": round(ach / peak, 4), "traffic": traffic,
+         "frac": round(ach / peak, 4), "traffic": None if traffic is None else traffic * chains,
          "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
-         "algorithmic_bytes_per_launch": 3 * B * 512 * (2 if fp16 else 4) + (B * 512 * 4 if (fp16 or x3) else 0) + 2 * 512 * 1536 * (2 if fp16 else 4),
-         "flop_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 4)}
+         "algorithmic_bytes_per_launch": alg_launch * chains,
+         "flop_per_launch": int(flops), "avg_launch_ms": round(avg_s * 1e3, 4), "concurrent_launches": chains,
+         "rows_per_launch": int(rows)}
+    if chains > 1:
+        r["achieved_one_launch"] = round(flops / avg_s / 1e12, 2)
+        r["note"] = (f"{chains} launches of this kernel (one per row-range chain, each on its own stream, {int(rows)} rows) overlap; achieved / traffic / "
+                     "algorithmic_bytes_per_launch are the CONCURRENT launches together over the average launch duration")
     if x3:
         r["peak_note"] = ("dense fp16 MFMA peak 2500 TFLOP/s / 3 (three fp16 MFMA products per fp32 product); executed MFMA rate = "
                           f"{round(3 * ach, 1)} TFLOP/s; the fp32 MFMA peak this replaces is {PEAK_FP32_MFMA_TFLOPS} TFLOP/s")
@@ -558,8 +573,8 @@ def compact_line(res, detail_path=None):
     rl = res.get("roofline")
     if rl:
         r = _pick(rl, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms", "flop_per_launch",
-                  "algorithmic_bytes_per_launch", "kernels_snapshot", "whole_pipeline_tflops", "whole_pipeline_frac_of_mfma_peak",
-                  "whole_pipeline_frac_of_hbm_peak")
+                  "concurrent_launches", "rows_per_launch", "achieved_one_launch", "algorithmic_bytes_per_launch", "kernels_snapshot",
+                  "whole_pipeline_tflops", "whole_pipeline_frac_of_mfma_peak", "whole_pipeline_frac_of_hbm_peak")
         if rl.get("traffic") and rl.get("algorithmic_bytes_per_launch"):
             r["traffic_over_algorithmic"] = round(rl["traffic"] / rl["algorithmic_bytes_per_launch"], 3)
         line["roofline"] = r

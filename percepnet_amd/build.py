@@ -88,6 +88,90 @@ def check_resources(remarks):
     return bad
 
 
+# ---- disassembly gate of the pitch kernel's hand-scheduled sequences (advisor, round 5) -----------------------------------------
+# pn_dsp_fe_split_p.hip issues its DPP adds and the LDS reads of the packed coarse loop from inline assembly, so the compiler's
+# hazard recogniser and s_waitcnt pass no longer see them.  Two properties the source relies on are checked in the ISA of every
+# build instead:
+#   (1) gfx9 hazard "VALU writes a VGPR -> a DPP instruction reads it as src0 (the operand routed through the cross-lane network):
+#       2 wait states".  Fails on any VALU write of vN followed by fewer than two wait states (an instruction = 1, s_nop k = k + 1)
+#       before a *_dpp instruction whose src0 is vN.
+#   (2) the packed coarse loop waits for its own LDS reads with hand-counted s_waitcnt lgkmcnt(4): LDS returns in order, SMEM does
+#       not — a scalar load inside that region would break the count.  Fails on any s_load / s_buffer_load between the first and
+#       the last v_pk_mul_f32 of pn_fe_pitch_kernel.
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+GATED_OBJECTS = ("pn_dsp_fe_split_p",)
+
+
+def disassemble_device_code(obj_path):
+    """gfx950 ISA text of the device code object bundled in a hipcc -c output (llvm-objdump --offloading + -d)."""
+    import shutil
+    import tempfile
+    objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump")
+    if not objdump:
+        raise RuntimeError("llvm-objdump not found: the disassembly gate cannot run")
+    with tempfile.TemporaryDirectory() as d:
+        local = os.path.join(d, os.path.basename(obj_path))
+        shutil.copy(obj_path, local)
+        subprocess.run([objdump, "--offloading", local], cwd=d, capture_output=True, text=True, check=True)
+        cos = [f for f in os.listdir(d) if "amdgcn" in f]
+        if not cos:
+            raise RuntimeError(f"no device code object in {obj_path}")
+        return subprocess.run([objdump, "-d", os.path.join(d, cos[0])], capture_output=True, text=True, check=True).stdout
+
+
+def _vregs(op):
+    """'v78' -> {78}; 'v[66:67]' -> {66, 67}; anything else -> set()"""
+    import re
+    m = re.fullmatch(r"v(\d+)", op)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def check_dpp_and_waitcnt(disasm):
+    """-> list of violations of the two hand-scheduling rules above in an llvm-objdump -d listing (empty = clean)."""
+    import re
+    bad = []
+    func, ins = None, []                              # per function: (mnemonic, [operands], text)
+    funcs = {}
+    for line in disasm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            func = m.group(1); ins = funcs.setdefault(func, [])
+            continue
+        t = line.split("//")[0].strip()
+        if func is None or not t or t.startswith("."):
+            continue
+        parts = t.split(None, 1)
+        ops = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", parts[1])] if len(parts) > 1 else []
+        ins.append((parts[0], ops, t))
+    for func, ins in funcs.items():
+        for i, (mn, ops, text) in enumerate(ins):
+            if "_dpp" not in mn or len(ops) < 2:
+                continue
+            src0 = _vregs(ops[1].split()[0])          # v_*_dpp vdst, src0 (DPP-routed), [src1] <modifiers glued to the last operand>
+            if not src0:
+                continue
+            states, j = 0, i - 1
+            while j >= 0 and states < 2:
+                pm, pops, ptext = ins[j]
+                if pm.startswith("v_") and pops and (_vregs(pops[0].split()[0]) & src0) and not pm.startswith(("v_cmp", "v_nop")):
+                    bad.append(f"{func}: `{ptext}` writes the DPP-routed src0 of `{text}` only {states} wait state(s) earlier (need 2)")
+                    break
+                states += (int(pops[0], 0) + 1) if (pm == "s_nop" and pops) else 1
+                j -= 1
+        if "pn_fe_pitch_kernel" in func:
+            pk = [i for i, x in enumerate(ins) if x[0] == "v_pk_mul_f32"]
+            if pk:
+                for mn, ops, text in ins[pk[0]:pk[-1] + 1]:
+                    if mn.startswith(("s_load_", "s_buffer_load")):
+                        bad.append(f"{func}: scalar load `{text}` inside the packed coarse loop (its hand-counted s_waitcnt lgkmcnt(4) assumes LDS reads only)")
+    return bad
+
+
 def toolchain_info(hipcc):
     try:
         out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
@@ -164,6 +248,15 @@ def build(force=False, verbose=True):
     bad = check_resources(resources)
     if bad:
         raise RuntimeError("register hygiene gate (build.RESOURCE_LIMITS) failed:\n  " + "\n  ".join(bad))
+    for base in GATED_OBJECTS:
+        o = os.path.join(LIBDIR, base + ".o")
+        stamp = o + ".isa_gate_ok"
+        if force or _stale(stamp, [o]):
+            viol = check_dpp_and_waitcnt(disassemble_device_code(o))
+            if viol:
+                raise RuntimeError("disassembly gate (build.check_dpp_and_waitcnt) failed — rebuild with -DPN_FP_DPP_ASM=0 -DPN_FP_COARSE_PK=0 or "
+                                   "fix the sequence:\n  " + "\n  ".join(viol[:20]))
+            open(stamp, "w").write("ok\n")
     if force or _stale(LIB, objs + [EXPORT_MAP]):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + EXPORT_MAP, "-o", LIB] + objs
         if verbose:

@@ -491,23 +491,24 @@ extern "C" int pn_ctx_synchronize(pn_ctx *c) { if (!c) return -1; PN_ON_DEVICE(c
 
 // ---- profiling ------------------------------------------------------------------------------------------
 struct Scope {
-  pn_ctx *c; int fam; hipEvent_t a, b; bool on;
-  Scope(pn_ctx *c_, int fam_) : c(c_), fam(fam_), on(c_->profiling) {
+  pn_ctx *c; int fam; hipEvent_t a, b; bool on; hipStream_t st;      // st: the stream the bracketed launches go to (a row-range chain's own)
+  Scope(pn_ctx *c_, int fam_, hipStream_t st_ = nullptr) : c(c_), fam(fam_), on(c_->profiling), st(st_ ? st_ : c_->stream) {
     if (on) {
       auto take = [&](hipEvent_t &e) { if (c->event_pool.empty()) hipEventCreate(&e); else { e = c->event_pool.back(); c->event_pool.pop_back(); } };
-      take(a); take(b); hipEventRecord(a, c->stream);
+      take(a); take(b); hipEventRecord(a, st);
     }
   }
   ~Scope() {
-    if (on) { hipEventRecord(b, c->stream); c->events.push_back({fam, a, b}); }
+    if (on) { hipEventRecord(b, st); c->events.push_back({fam, a, b}); }
     // debugging aid: PERCEPNET_SYNC_EACH=<bit mask over kernel families, -1 = all>: host sync after those launches
     static const long sync_mask = getenv("PERCEPNET_SYNC_EACH") ? strtol(getenv("PERCEPNET_SYNC_EACH"), NULL, 0) : 0;
-    if (sync_mask & (1L << fam)) hipStreamSynchronize(c->stream);
+    if (sync_mask & (1L << fam)) hipStreamSynchronize(st);
   }
 };
 
 static int flush_events(pn_ctx *c) {
   PN_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int k = 1; k < 4; k++) if (c->chain_stream[k]) PN_HIP_CHECK(hipStreamSynchronize(c->chain_stream[k]));
   for (auto &e : c->events) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->fam_ms[e.fam] += ms; c->fam_n[e.fam]++; }
@@ -566,9 +567,9 @@ static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
 // Returns 0, or -1 when a launcher refused its geometry (pn_set_error names it): the refused layer is not launched (later
 // layers of the frame may be — their results are never reported) and the caller fails the frame.
 // The ten layers for the rows [r0, r0 + nrows) of the batch on stream `st`.  Every activation buffer is row-major, so a row range
-// is the same launch with every base pointer moved down by r0 rows.  small / small_gru: the kernel family; quiet: no profiling
-// brackets (they are recorded on the context's own stream).  The shadow-operand and STRICT modes always run the whole batch.
-static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, int small, int small_gru, bool quiet) {
+// is the same launch with every base pointer moved down by r0 rows.  small / small_gru: the kernel family.  The shadow-operand
+// and STRICT modes always run the whole batch.
+static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, int small, int small_gru) {
   const size_t Bp = c->Bp; const int strict = c->nn_mode == PN_NN_STRICT; const int64_t t = c->tn;
   const int B = (int)nrows;
   // x3: the layers that run on the fp16 matrix cores from operand shadows — split precision (hi + lo planes) or fp16 operands (hi only)
@@ -577,28 +578,30 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
   const float *tab = c->tansig;
   int rc = 0;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
-  struct MaybeScope { char buf[sizeof(Scope)]; Scope *s; MaybeScope(pn_ctx *c_, int fam, bool q) : s(q ? NULL : new (buf) Scope(c_, fam)) {} ~MaybeScope() { if (s) s->~Scope(); } };
+  // every chain's launches are bracketed on the stream they go to (pn_ctx_kernel_times averages over all launches of a family;
+  // with N chains the launches of one family overlap in time: bench.py prices the CONCURRENT launches together)
+  struct MaybeScope { Scope s; MaybeScope(pn_ctx *c_, int fam, hipStream_t st_) : s(c_, fam, st_) {} };
   float *c1new = c->c1ring + (size_t)(t % 5) * Bp * 128 + r0 * 128;
   float *c2new = c->c2ring + (size_t)(t % 3) * Bp * 512 + r0 * 512;
   float *c2out = c->c2out + r0 * 512, *gr = c->gr + r0 * 68;
-  { MaybeScope sc(c, KF_FC, quiet);
+  { MaybeScope sc(c, KF_FC, st);
     PnSegs A = seg1(c->feat + r0 * PN_FEAT_STRIDE, PN_FEAT_STRIDE, strict ? PN_NFEAT : PN_FEAT_STRIDE);   // cols 70..127 are zero
     if (c->inject_bad_launch && !strict) A.width[0] = 96;   // test hook: three K-tiles, which every MFMA dense launcher refuses
     rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC].w, c->L[PN_L_FC].wp, c->L[PN_L_FC].bias, 128, c->geom[PN_L_FC].act, tab, c1new, 128, B, small);
     if (x3) rc |= pn_launch_split_x3(st, c1new, 128, 128, shadow(c, c1new), (int)Bp, np); }   // fc runs in fp32 (70 inputs); its output enters the shadow-operand layers
-  { MaybeScope sc(c, KF_CONV1, quiet);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
+  { MaybeScope sc(c, KF_CONV1, st);   // causal conv as dense over [4 previous fc outputs | current] (nnet.cpp:182-200)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     for (int j = 0; j < 5; j++) { A.p[j] = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128 + r0 * 128; A.ld[j] = 128; A.width[j] = 128; }
     if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, shadow(c, c2new), 16, B, c->x3_rg, np);
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_CONV1].w, c->L[PN_L_CONV1].wp, c->L[PN_L_CONV1].bias, 512, c->geom[PN_L_CONV1].act, tab, c2new, 512, B, small); }
-  { MaybeScope sc(c, KF_CONV2, quiet);
+  { MaybeScope sc(c, KF_CONV2, st);
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512 + r0 * 512; A.ld[j] = 512; A.width[j] = 512; }
     if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c2out, 512, c->c2outH, 16, B, c->x3_rg, np);
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c2out, 512, B, small); }
   const float *x = c2out;
   for (int i = 0; i < 4 && !rc; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
-    MaybeScope sc(c, KF_GRU512, quiet);
+    MaybeScope sc(c, KF_GRU512, st);
     const int li = PN_L_GRU1 + i;
     float *ho = c->gru[i] + (size_t)cur * Bp * 512 + r0 * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512 + r0 * 512;
     PnSegs X = seg1(x, 512, 512);
@@ -609,20 +612,20 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
   const float *g1 = c->gru[0] + (size_t)nxt * Bp * 512 + r0 * 512, *g2 = c->gru[1] + (size_t)nxt * Bp * 512 + r0 * 512,
               *g3 = c->gru[2] + (size_t)nxt * Bp * 512 + r0 * 512, *gb = c->gru[3] + (size_t)nxt * Bp * 512 + r0 * 512;
   float *rbo = c->rb + (size_t)cur * Bp * 128 + r0 * 128, *rbn = c->rb + (size_t)nxt * Bp * 128 + r0 * 128;
-  { MaybeScope sc(c, KF_GRU_RB, quiet);   // input = [gru3 | conv2 out] (rnn.cpp:67-69)
+  { MaybeScope sc(c, KF_GRU_RB, st);   // input = [gru3 | conv2 out] (rnn.cpp:67-69)
     PnSegs X; memset(&X, 0, sizeof(X)); X.n = 2;
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
     if (x3) rc |= pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), B, c->x3_rg, np);
     else rc |= pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, B, small); }   // gru_rb (1024->128) crosses over with the dense layers
-  { MaybeScope sc(c, KF_FC_GB, quiet);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
+  { MaybeScope sc(c, KF_FC_GB, st);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
     const float *ps[5] = {c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
     if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, NULL, 0, B, c->x3_rg, np);
     else if (c->L[PN_L_FC_GB].wq) rc |= pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, B);
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, B, small); }
-  { MaybeScope sc(c, KF_FC_RB, quiet);
+  { MaybeScope sc(c, KF_FC_RB, st);
     PnSegs A = seg1(rbn, 128, 128);
     if (c->L[PN_L_FC_RB].wq) rc |= pn_launch_dense_n16(st, A, c->L[PN_L_FC_RB].wq, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, gr + 34, 68, B);
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC_RB].w, c->L[PN_L_FC_RB].wp, c->L[PN_L_FC_RB].bias, 34, c->geom[PN_L_FC_RB].act, tab, gr + 34, 68, B, small); }
@@ -670,7 +673,7 @@ static int chain_streams_init(pn_ctx *c, int n) {
 }
 static int launch_rnn(pn_ctx *c) {
   const int n = nn_chains_of(c);
-  if (n <= 1) return launch_rnn_rows(c, 0, c->B, c->stream, c->small, c->small_gru, false);
+  if (n <= 1) return launch_rnn_rows(c, 0, c->B, c->stream, c->small, c->small_gru);
   if (chain_streams_init(c, n)) return -1;
   // row ranges: equal shares rounded up to whole 128-row tiles; the last chain takes what is left
   const size_t B = c->B, share = ((B + n - 1) / n + 127) / 128 * 128;
@@ -681,7 +684,7 @@ static int launch_rnn(pn_ctx *c) {
     if (!nr) continue;
     hipStream_t st = k ? c->chain_stream[k] : c->stream;
     if (k) PN_HIP_CHECK(hipStreamWaitEvent(st, c->chain_fork, 0));
-    rc |= launch_rnn_rows(c, r0, nr, st, c->small, c->small_gru, k != 0);   // profiling brackets on the context's stream only
+    rc |= launch_rnn_rows(c, r0, nr, st, c->small, c->small_gru);
     if (k) PN_HIP_CHECK(hipEventRecord(c->chain_join[k], st));             // also after a refused launch: nothing stays unordered
   }
   for (int k = 1; k < n; k++) PN_HIP_CHECK(hipStreamWaitEvent(c->stream, c->chain_join[k], 0));

@@ -108,3 +108,40 @@ def test_model_from_file_and_free_are_safe_on_foreign_input(lib, blob, tmp_path)
     foreign = (ctypes.c_char * 80)()
     lib.rnnoise_model_free_c(ctypes.addressof(foreign)); lib.rnnoise_model_free_c(None)
     lib.rnnoise_model_free_c(m); lib.rnnoise_model_free_c(m)     # second call: no longer registered, nothing happens
+
+
+def test_disassembly_gate_of_the_hand_scheduled_pitch_kernel():
+    """Advisor (round 5, medium): the pitch kernel's DPP adds and the LDS reads of its packed coarse loop come from inline assembly, out
+    of sight of the compiler's hazard recogniser and s_waitcnt pass.  build.check_dpp_and_waitcnt checks the ISA of every build: no VALU
+    write within two wait states of a DPP read of that register as src0, no scalar load inside the packed coarse loop.  Here: the
+    checker finds planted violations in a synthetic listing, and the object of THIS build is clean (build() fails otherwise)."""
+    from percepnet_amd import build
+    fake = """
+0000000000001000 <pn_fe_pitch_kernel>:
+	v_mul_f32_e32 v5, v1, v2                                // 000000001000: 0A0A0501
+	v_add_f32_dpp v7, v5, v7 row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1// 000000001004: 020E0EFA FF095005
+	v_mul_f32_e32 v9, v1, v2                                // 00000000100C: 0A120501
+	s_nop 1                                                    // 000000001010: BF800001
+	v_add_f32_dpp v7, v9, v7 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1// 000000001014
+	v_mul_f32_e32 v12, v1, v2                               // one instruction between = 1 wait state: still too close
+	v_mov_b32_e32 v20, v21
+	v_subrev_f32_dpp v7, v12, v7 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_pk_mul_f32 v[36:37], v[34:35], v[42:43] op_sel:[1,0]
+	s_load_dwordx2 s[4:5], s[0:1], 0x0
+	v_pk_mul_f32 v[36:37], v[34:35], v[42:43] op_sel:[1,0]
+	v_pk_add_f32 v[10:11], v[36:37], v[42:43]
+	v_mov_b32_dpp v3, v11 row_ror:1 row_mask:0xf bank_mask:0xf
+	ds_read_b32 v30, v31
+	v_add_f32_dpp v7, v30, v7 row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1
+"""
+    bad = build.check_dpp_and_waitcnt(fake)
+    assert len(bad) == 4, bad
+    assert "v5" in bad[0] and "0 wait state" in bad[0]
+    assert "v12" in bad[1] and "1 wait state" in bad[1]
+    assert "v[10:11]" in bad[2]
+    assert "scalar load" in bad[3] and "s_load_dwordx2" in bad[3]
+    build.build(verbose=False)
+    obj = os.path.join(build.LIBDIR, "pn_dsp_fe_split_p.o")
+    isa = build.disassemble_device_code(obj)
+    assert isa.count("_dpp") > 500 and "v_pk_mul_f32" in isa          # the hand-scheduled sequences are really there
+    assert build.check_dpp_and_waitcnt(isa) == []
