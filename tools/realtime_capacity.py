@@ -196,8 +196,17 @@ def paced_realtime(api, synth, model, dev_index, B, nn_mode, seconds=10.0, ctx=N
                     if a_t - now > 0.0004:
                         time.sleep(0.0002)
                 if stall is not None and t == stall[0]:
-                    time.sleep(stall[1] * 1e-3)                # the injected host hiccup
-                    now = time.perf_counter()
+                    # the injected host hiccup: the SUBMIT path is held back for stall[1] ms.  Deliveries keep being stamped
+                    # meanwhile (a frame that lands during the hiccup landed on time: with a blind poller frames t-1 / t-2 of
+                    # every batch whose frame takes more than ~10 ms door to door were stamped 50 ms late — round 6's first
+                    # capacity search failed every size above 49 152 on "not clean before the stall" for that reason)
+                    t_res = time.perf_counter() + stall[1] * 1e-3
+                    while True:
+                        now = time.perf_counter()
+                        poll(now)
+                        if now >= t_res:
+                            break
+                        time.sleep(0.0002)
                 arrive[t] = a_t; start[t] = now
                 ctx.submit_host_i16(*bufs[t % 3])
                 ret[t] = time.perf_counter()
