@@ -844,16 +844,18 @@ def main():
         sustained["rank"] = rank
     # The real-time claim, measured: frames arriving every 10.000 ms on the host through the pipelined host path (each rank
     # its own pinned buffers, allocated after its NUMA binding).  N = 1, headline workload: the STRICT verdict at this batch
-    # size (tools/realtime_capacity.py: `--realtime-runs` undisturbed runs, none forgiven, + one run with an injected host stall;
-    # one fallback size when it fails; `--full` = the search over the 512-stream grid + confirmation run).  Otherwise one paced
+    # size and at one size above it (tools/realtime_capacity.py: `--realtime-runs` undisturbed runs, none forgiven, + one run with an
+    # injected host stall; one fallback size when it fails; `--full` = the search over the 512-stream grid + confirmation run).  Otherwise one paced
     # run at this batch size on every rank at the same time.
     realtime_rank, capacity = None, None
     if not (a.strict or a.no_sustained or a.no_realtime):
         sharding.barrier(dist)
         if headline:
             soak = a.realtime_soak_seconds if a.realtime_soak_seconds is not None else (20.0 if a.full else 0.0)
+            # default: the workload's own batch size and ONE size above it (66 560: two 512-stream steps, defended with margin on
+            # every box seen — tools/realtime_capacity.py's search goes further, profiles/r06_realtime_capacity.log), one fallback below
             capacity = realtime_capacity(api, synth, model, local_rank, nn_mode, a.realtime_seconds, a.realtime_runs, log, soak_seconds=soak,
-                                         **({} if a.full else {"grid": [B], "fallback": (61440,)}))
+                                         **({} if a.full else {"grid": [B, B + 1024], "fallback": (61440,)}))
             at_b = [r for r in capacity["paced_runs"] if r.get("streams") == B and not r.get("recovery")]
             realtime_rank = at_b[0] if at_b else None
         else:

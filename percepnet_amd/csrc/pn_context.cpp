@@ -647,7 +647,10 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
 static int nn_chains_of(const pn_ctx *c) {
   if (c->nn_mode != PN_NN_MFMA || c->small || c->small_gru) return 1;
   const char *e = getenv("PN_NN_CHAINS");
-  int n = e ? atoi(e) : (c->B > 16384 ? 2 : 1);
+  // default: two chains for a batch that is NOT a whole number of rounds of the 512-wide layers (4096 rows).  An exact fit gains
+  // little (9.39 -> 9.37 ms at 65 536 streams) and a second compute stream is one more hardware queue for the pipelined host path's
+  // copy streams to stay clear of (HIP has four by default): the headline configuration keeps one chain
+  int n = e ? atoi(e) : ((c->B > 16384 && c->B % 4096 != 0) ? 2 : 1);
   if (n < 1) n = 1;
   if (n > PN_MAX_CHAINS) n = PN_MAX_CHAINS;
   while (n > 1 && (size_t)c->B < (size_t)n * 4096) n--;      // a chain of fewer than 4096 rows is the small-batch regime: not worth a stream
@@ -657,15 +660,21 @@ static int nn_chains_of(const pn_ctx *c) {
 // and on a queue shared with the context's stream a chain runs in front of the others instead of beside them.  Same remedy as for
 // the copy streams of the pipelined host path: default-priority streams PROBED against the streams they must not share a queue
 // with, a high-priority one as the fallback (pipe_make_stream).
-static int pipe_make_stream(pn_ctx *c, hipStream_t *out, char how, int prio, char fallback, std::initializer_list<hipStream_t> others, char *kind);
+static int pipe_make_stream(pn_ctx *c, hipStream_t *out, char how, int prio, char fallback, const std::vector<hipStream_t> &others, char *kind);
+// every stream of this context that carries kernels or copies of a frame: a new one must share a hardware queue with none of them
+static std::vector<hipStream_t> busy_streams(const pn_ctx *c) {
+  std::vector<hipStream_t> v{c->stream};
+  for (int k = 1; k < 4; k++) if (c->chain_stream[k]) v.push_back(c->chain_stream[k]);
+  if (c->pipe.h2d) v.push_back(c->pipe.h2d);
+  if (c->pipe.d2h) v.push_back(c->pipe.d2h);
+  return v;
+}
 static int chain_streams_init(pn_ctx *c, int n) {
   int lo = 0, hi = 0;
   PN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   for (int k = 1; k < n; k++) {
     if (c->chain_stream[k]) continue;
-    if (k == 1) { if (pipe_make_stream(c, &c->chain_stream[k], 'a', hi, 'h', {c->stream}, &c->chain_kind[k])) return -1; }
-    else if (k == 2) { if (pipe_make_stream(c, &c->chain_stream[k], 'a', hi, 'h', {c->stream, c->chain_stream[1]}, &c->chain_kind[k])) return -1; }
-    else { if (pipe_make_stream(c, &c->chain_stream[k], 'a', hi, 'h', {c->stream, c->chain_stream[1], c->chain_stream[2]}, &c->chain_kind[k])) return -1; }
+    if (pipe_make_stream(c, &c->chain_stream[k], 'a', hi, 'h', busy_streams(c), &c->chain_kind[k])) return -1;
     PN_HIP_CHECK(hipEventCreateWithFlags(&c->chain_join[k], hipEventDisableTiming));
   }
   if (!c->chain_fork) PN_HIP_CHECK(hipEventCreateWithFlags(&c->chain_fork, hipEventDisableTiming));
@@ -1029,7 +1038,7 @@ static int pipe_streams_share(pn_ctx *c, hipStream_t busy, hipStream_t cand, voi
 // One copy stream.  how: 'n' default priority unprobed, 'h' / 'l' a priority stream, 'a' (the default) a default-priority
 // stream that shares its queue with none of `others` — up to 6 candidates (the rejected ones stay alive until the end, so
 // that the runtime's least-used-queue choice moves on), else the priority stream `fallback`.
-static int pipe_make_stream(pn_ctx *c, hipStream_t *out, char how, int prio, char fallback, std::initializer_list<hipStream_t> others, char *kind) {
+static int pipe_make_stream(pn_ctx *c, hipStream_t *out, char how, int prio, char fallback, const std::vector<hipStream_t> &others, char *kind) {
   if (how == 'h' || how == 'l') {
     int lo = 0, hi = 0;
     PN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1080,8 +1089,8 @@ static int pipe_init_body(pn_ctx *c) {
   PN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   const char *pp = getenv("PN_PIPE_PRIO");
   if (pp && strlen(pp) != 2) pp = NULL;
-  if (pipe_make_stream(c, &P.h2d, pp ? pp[0] : 'a', prio_greatest, 'h', {c->stream}, &P.kind[0])) return -1;
-  if (pipe_make_stream(c, &P.d2h, pp ? pp[1] : 'a', prio_least, 'l', {c->stream, P.h2d}, &P.kind[1])) return -1;
+  if (pipe_make_stream(c, &P.h2d, pp ? pp[0] : 'a', prio_greatest, 'h', busy_streams(c), &P.kind[0])) return -1;     // incl. the row-range chains' streams
+  if (pipe_make_stream(c, &P.d2h, pp ? pp[1] : 'a', prio_least, 'l', busy_streams(c), &P.kind[1])) return -1;
   for (int k = 0; k < 2; k++) {
     PN_HIP_CHECK(hipEventCreateWithFlags(&P.in_ready[k], hipEventDisableTiming));
     PN_HIP_CHECK(hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
