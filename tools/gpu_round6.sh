@@ -27,5 +27,8 @@ if [ "$MODE" != "tests" ]; then
 fi
 if [ "$MODE" = "all" ] || [ "$MODE" = "bench" ]; then
   bash tools/gpu_bench_lines.sh $TAG side
+  T0=$(date +%s); timeout 1200 python bench.py --full --detail-out $O/bench_${TAG}_full_detail.json > $O/bench_${TAG}_full.json 2>> $O/bench_$TAG.err
+  echo "bench.py --full wall seconds: $(( $(date +%s) - T0 ))" | tee -a $O/bench_${TAG}_wall.txt
+  timeout 900 python tools/tail_sweep.py 1 2 > $O/${TAG}_row_chains_sweep.log 2>&1; tail -4 $O/${TAG}_row_chains_sweep.log
   ls $O/prof_summary
 fi
