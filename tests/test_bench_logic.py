@@ -230,10 +230,14 @@ def test_profile_summaries_keep_only_the_steady_state_frames(tmp_path):
 
 
 def test_design_table_is_generated_from_the_committed_bench_lines():
-    """DESIGN.md's status table is what tools/design_table.py makes of profiles/r05_bench*.json (numbers cannot go stale)."""
+    """DESIGN.md's status table is what tools/design_table.py makes of profiles/r06_bench*_detail.json (numbers cannot go stale), and
+    the committed compact line of that run is the line bench.compact_line makes of the committed full record."""
     s = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, b = s.index("<!-- BEGIN GENERATED"), s.index("<!-- END GENERATED -->")
     block = s[a:b]
-    d = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench.json")) if l.startswith("{")][-1])
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
     assert f"| {d['ms_per_step']} |" in block and f"{d['value']:.0f}" in block
     assert str(d["realtime_streams_p99"]) in block and d["roofline"]["kernels_snapshot"] in block
+    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r06_bench.json")) if l.startswith("{")][-1])
+    assert line["value"] == d["value"] and line["roofline"]["frac"] == d["roofline"]["frac"] and line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
+    assert line["realtime_streams_p99"] == d["realtime_streams_p99"]

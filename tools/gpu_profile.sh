@@ -16,7 +16,7 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o 
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $B --steps $K --warmup $W --no-profile > /dev/null 2> $OUT/pmc_write.err
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- $B --steps $K --warmup $W --no-profile > /dev/null 2> $OUT/pmc_sq.err
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -o bench -- $B --steps $K --warmup $W --no-profile > /dev/null 2> $OUT/pmc_sq2.err
-python $R/tools/summarize_prof.py $TAG --suffix "$SUF" --src $OUT --out $R/gpurun_out/prof_summary --frames-total $((W + K)) --frames-keep $K
+python $R/tools/summarize_prof.py $TAG --suffix "$SUF" --src $OUT --out $R/gpurun_out/prof_summary --frames-total $((${PN_PROF_PRIME:-12} + W + K)) --frames-keep $K
 # the raw kernel trace of a full run is large: keep only the summaries
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*.db" -delete
