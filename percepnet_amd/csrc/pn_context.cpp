@@ -647,10 +647,14 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
 static int nn_chains_of(const pn_ctx *c) {
   if (c->nn_mode != PN_NN_MFMA || c->small || c->small_gru) return 1;
   const char *e = getenv("PN_NN_CHAINS");
-  // default: two chains for a batch that is NOT a whole number of rounds of the 512-wide layers (4096 rows).  An exact fit gains
-  // little (9.39 -> 9.37 ms at 65 536 streams) and a second compute stream is one more hardware queue for the pipelined host path's
-  // copy streams to stay clear of (HIP has four by default): the headline configuration keeps one chain
-  int n = e ? atoi(e) : ((c->B > 16384 && c->B % 4096 != 0) ? 2 : 1);
+  // default: two chains unless the batch fits EVERY layer's rounds exactly — a multiple of 32 768 streams (8 rounds of the 512-wide
+  // layers, 2 of the 128-wide GRU) whose 128-row tile count also fits the 34-wide layers' single column block (<= 512 tiles or a
+  // multiple of 512): 32 768, 65 536, 131 072, ...  Measured (profiles/r06_row_chains.log): two chains win 0.6-2 % at 20 480, 49 152,
+  // 61 440, 69 632 and every size off the 4096-stream grid, and change nothing at 32 768 / 65 536 (+-0.03 ms) — where a second compute
+  // stream would only be one more hardware queue for the pipelined host path's copy streams to stay clear of (HIP has four by default)
+  const size_t mt = ((size_t)c->B + 127) / 128;
+  const bool exact = (c->B % 32768 == 0) && (mt <= 512 || mt % 512 == 0);
+  int n = e ? atoi(e) : ((c->B > 16384 && !exact) ? 2 : 1);
   if (n < 1) n = 1;
   if (n > PN_MAX_CHAINS) n = PN_MAX_CHAINS;
   while (n > 1 && (size_t)c->B < (size_t)n * 4096) n--;      // a chain of fewer than 4096 rows is the small-batch regime: not worth a stream
