@@ -20,7 +20,7 @@ RUN = os.path.join(LIBDIR, "percepnet_run")
 EXPORT_MAP = os.path.join(CSRC, "libpercepnet_hip.map")    # ld version script: the export list (everything else is local)
 RELINKED = os.path.join(LIBDIR, "percepNet_run_relinked")    # reference src/main.cpp, untouched, linked against LIB
 REFERENCE_SRC = os.environ.get("PERCEPNET_REFERENCE_SRC", "/root/reference/src")
-SOURCES = ["pn_tables.cpp", "pn_model.cpp", "pn_pack.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_targets.hip", "pn_state.hip", "pn_active.hip", "pn_context.cpp",
+SOURCES = ["pn_tables.cpp", "pn_model.cpp", "pn_pack.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_nn_d.hip", "pn_targets.hip", "pn_state.hip", "pn_active.hip", "pn_context.cpp",
            "pn_featgen.cpp", "rnnoise_compat.cpp"]
 # percepnet_run.cpp / percepnet_featgen.cpp (the CLIs) are linked separately against the library
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
@@ -33,7 +33,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # -pragma-unroll-threshold: the paired-phase GRU kernel's epilogue phase is ONE fully unrolled loop over its 32 / 36 barrier steps
 # (every step then has compile-time register sets, ring slots and tile numbers); the default limit of `#pragma unroll` (16 K
 # IR instructions, counted before the per-step branches fold) silently leaves it rolled — with every array in scratch
-EXTRA_FLAGS = {"pn_nn_x3.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]}
+EXTRA_FLAGS = {"pn_nn_x3.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"],
+               "pn_nn_d.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -55,8 +56,9 @@ EXPECTED_HIP = "7.2"
 RESOURCE_LIMITS = {"pn_fe_spec_in_kernel": (0, 0), "pn_fe_spec_out_kernel": (0, 40), "pn_fe_pitch_kernel": (0, 48),
                    "pn_backend_kernel": (0, 64),
                    # shadow-operand network kernels: everything in registers (a staging array once went to scratch: +30 % time)
-                   "pn_gru_x3_kernel": (0, 0), "pn_dense_x3_kernel": (0, 0)}
-RESOURCE_SOURCES = ("pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn_x3.hip")
+                   "pn_gru_x3_kernel": (0, 0), "pn_dense_x3_kernel": (0, 0),
+                   "pn_gru_d_kernel": (0, 0)}
+RESOURCE_SOURCES = ("pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn_x3.hip", "pn_nn_d.hip")
 
 
 def parse_resource_remarks(text):

@@ -53,6 +53,8 @@ struct pn_ctx {
   int device, B, nn_mode;
   int x3_rg;                       // split-precision mode: row groups of 32 per wave (1: 128-row blocks, 2: 256-row blocks), fixed at creation from B
   int small, small_gru;            // network kernel family per layer kind: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
+  int direct;                      // fp32 MFMA mode, large batches: 1 = the direct-operand family (pn_nn_d.hip: A fragments from fp32 shadows,
+                                   // 64 rows per wave when x3_rg == 2); fixed at creation from B, never together with small / small_gru
   int fe_mode;                     // front end: FE_SPLIT = three phase kernels (pn_dsp_fe_split_*.hip); FE_MONO_G4 / FE_MONO_G2 = the
                                    // single-launch kernel with four / two streams per wavefront (pn_dsp_fe.hip, pn_dsp_fe_g2.hip)
   size_t Bp;                       // B rounded up to the largest GEMM M tile (256): row count of every network buffer
@@ -148,7 +150,8 @@ static int upload_w(pn_ctx *c, SharedWeights *w, float **dst, const float *src, 
 }
 
 // operand shadows: 1 half per element (fp16-operand mode) or a hi and a lo plane (split-precision mode)
-static size_t shadow_halfs_per_element(const pn_ctx *c) { return c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1; }
+// (the fp32 shadows of the direct-operand family are 4 bytes per element, laid out in the same 16-byte slab entries)
+static size_t shadow_halfs_per_element(const pn_ctx *c) { return (c->nn_mode == PN_NN_MFMA_X3 || c->direct) ? 2 : 1; }
 static bool x3_layer(int li) { return li == PN_L_CONV1 || li == PN_L_CONV2 || li == PN_L_GRU_RB || li == PN_L_FC_GB || (li >= PN_L_GRU1 && li < PN_L_GRU1 + 4); }
 static int zero_state(pn_ctx *c) {
   const size_t B = c->B;
@@ -167,10 +170,10 @@ static int zero_state(pn_ctx *c) {
   for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gru[i], 0, 2 * Bp * 512 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->rb, 0, 2 * Bp * 128 * 4, c->stream));
   PN_HIP_CHECK(hipMemsetAsync(c->gr, 0, B * 68 * 4, c->stream));
-  if (c->c1ringH) {
+  if (c->c2outH) {
     const size_t hb = 2 * shadow_halfs_per_element(c);   // shadow bytes per element
-    PN_HIP_CHECK(hipMemsetAsync(c->c1ringH, 0, 5 * Bp * 128 * hb, c->stream));
-    PN_HIP_CHECK(hipMemsetAsync(c->c2ringH, 0, 3 * Bp * 512 * hb, c->stream));
+    if (c->c1ringH) PN_HIP_CHECK(hipMemsetAsync(c->c1ringH, 0, 5 * Bp * 128 * hb, c->stream));
+    if (c->c2ringH) PN_HIP_CHECK(hipMemsetAsync(c->c2ringH, 0, 3 * Bp * 512 * hb, c->stream));
     PN_HIP_CHECK(hipMemsetAsync(c->c2outH, 0, Bp * 512 * hb, c->stream));
     for (int i = 0; i < 4; i++) PN_HIP_CHECK(hipMemsetAsync(c->gruH[i], 0, 2 * Bp * 512 * hb, c->stream));
     PN_HIP_CHECK(hipMemsetAsync(c->rbH, 0, 2 * Bp * 128 * hb, c->stream));
@@ -203,7 +206,7 @@ static int dsp_selftest(pn_ctx *c);
 static int nn_chains_of(const pn_ctx *c);
 static int chain_streams_init(pn_ctx *c, int n);
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru, int force_x3_rg = 0, int force_n16 = -1);
+                          int force_small, int force_small_gru, int force_x3_rg = 0, int force_n16 = -1, int force_direct = -1);
 
 extern "C" void pn_ctx_destroy(pn_ctx *c) {
   if (!c) return;
@@ -299,7 +302,7 @@ fail_w:
 // force_small / force_small_gru: -1 = choose the network kernel family from the batch size (the public behaviour);
 // 0 / 1 = the self-test's temporary contexts run the SAME family as the context under test whatever their own size.
 static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int nn_mode, void *hip_stream, bool selftest,
-                          int force_small, int force_small_gru, int force_x3_rg, int force_n16) {
+                          int force_small, int force_small_gru, int force_x3_rg, int force_n16, int force_direct) {
   if (!model) { pn_set_error("NULL model"); return NULL; }
   if (n_streams < 1) { pn_set_error("n_streams must be >= 1"); return NULL; }
   if (nn_mode != PN_NN_MFMA && nn_mode != PN_NN_STRICT && nn_mode != PN_NN_MFMA_F16 && nn_mode != PN_NN_MFMA_X3) { pn_set_error("bad nn_mode %d", nn_mode); return NULL; }
@@ -312,7 +315,10 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   DeviceGuard _dg(device);
   if (!_dg.ok) { pn_set_error("hipSetDevice(%d) failed", device); return NULL; }
   pn_ctx *c = new pn_ctx();
-  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_mode = pn_fe_mode_for(n_streams); c->x3_rg = force_x3_rg ? force_x3_rg : pn_x3_rg_for(n_streams); c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
+  c->device = device; c->B = n_streams; c->Bp = ((size_t)n_streams + 255) / 256 * 256; c->nn_mode = nn_mode; c->small = force_small >= 0 ? force_small : n_streams <= pn_small_rows(); c->small_gru = force_small_gru >= 0 ? force_small_gru : n_streams <= pn_small_gru_rows(); c->fe_mode = pn_fe_mode_for(n_streams); c->x3_rg = force_x3_rg ? force_x3_rg : pn_x3_rg_for(n_streams);
+  c->direct = (nn_mode == PN_NN_MFMA && !c->small && !c->small_gru) ? (force_direct >= 0 ? force_direct : pn_direct_for(n_streams)) : 0;
+  if (c->direct) c->x3_rg = force_x3_rg ? (force_x3_rg >= 2 ? 2 : 1) : pn_direct_rg_for(n_streams);
+  c->t = 0; c->tn = 0; c->bytes = 0; c->profiling = false;
   memset(c->fam_ms, 0, sizeof(c->fam_ms)); memset(c->fam_n, 0, sizeof(c->fam_n));
   memset(c->L, 0, sizeof(c->L));
   c->c1ringH = c->c2ringH = c->c2outH = c->rbH = NULL; memset(c->gruH, 0, sizeof(c->gruH));
@@ -348,10 +354,12 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   for (int i = 0; i < 4; i++) DEV_ALLOC(c->gru[i], 2 * Bp * 512, false);
   DEV_ALLOC(c->rb, 2 * Bp * 128, false);
   DEV_ALLOC(c->gr, B * 68, false);
-  if (nn_mode == PN_NN_MFMA_F16 || nn_mode == PN_NN_MFMA_X3) {
-    const size_t hp = shadow_halfs_per_element(c);      // 1: fp16 shadow; 2: hi + lo planes (split precision)
-    DEV_ALLOC(c->c1ringH, hp * 5 * Bp * 128, false);
-    DEV_ALLOC(c->c2ringH, hp * 3 * Bp * 512, false);
+  if (nn_mode == PN_NN_MFMA_F16 || nn_mode == PN_NN_MFMA_X3 || c->direct) {
+    const size_t hp = shadow_halfs_per_element(c);      // 1: fp16 shadow; 2: hi + lo planes (split precision) / fp32 fragments (direct-operand GRUs)
+    if (!c->direct) {                                   // (the direct-operand family keeps its dense layers on the batch kernels: no shadows of the conv FIFOs)
+      DEV_ALLOC(c->c1ringH, hp * 5 * Bp * 128, false);
+      DEV_ALLOC(c->c2ringH, hp * 3 * Bp * 512, false);
+    }
     DEV_ALLOC(c->c2outH, hp * Bp * 512, false);
     for (int i = 0; i < 4; i++) DEV_ALLOC(c->gruH[i], hp * 2 * Bp * 512, false);
     DEV_ALLOC(c->rbH, hp * 2 * Bp * 128, false);
@@ -447,7 +455,7 @@ extern "C" int pn_ctx_reset_streams(pn_ctx *c, const int32_t *ids, int n) {
   for (int i = 0; i < 4; i++) pn_launch_zero_rows(st, c->gru[i], 512, 512, 2, Bp * 512, d, n);
   pn_launch_zero_rows(st, c->rb, 128, 128, 2, Bp * 128, d, n);
   pn_launch_zero_rows(st, c->gr, 68, 68, 1, 0, d, n);
-  if (c->c1ringH) {                                        // operand shadows of the fp16-operand / split-precision modes
+  if (c->c2outH) {                                         // operand shadows (fp16-operand / split-precision modes, direct-operand GRUs); a NULL one is skipped
     const int np = (int)shadow_halfs_per_element(c);
     pn_launch_zero_shadow_rows(st, c->c1ringH, 128, np, 5, np * Bp * 128, d, n);
     pn_launch_zero_shadow_rows(st, c->c2ringH, 512, np, 3, np * Bp * 512, d, n);
@@ -474,8 +482,9 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   // rows per wave (conv1, conv2, GRUs, fc_gb); x3_rg 3 = 64 rows with the GRUs on the paired-phase kernel (pn_gru_x3p_kernel)
   const char *xk = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg >= 2 ? "x3_rows64" : "x3_rows32") : (c->x3_rg >= 2 ? "f16_rows64" : "f16_rows32");
   const char *xg = c->nn_mode == PN_NN_MFMA_X3 ? (c->x3_rg == 3 ? "x3_rows64_paired" : xk) : (c->x3_rg == 3 ? "f16_rows64_paired" : xk);
+  const char *dk = c->x3_rg >= 2 ? "direct_rows64" : "direct_rows32";      // direct-operand fp32 GRU kernels (pn_nn_d.hip); the dense layers stay "batch"
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s weights=%s nn_chains=%d%s%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
-                         x3 ? xg : (fam && c->small_gru ? "small" : "batch"), x3 ? xg : (fam && c->small ? "small" : "batch"),
+                         x3 ? xg : (c->direct ? dk : (fam && c->small_gru ? "small" : "batch")), x3 ? xg : (c->direct ? dk : (fam && c->small ? "small" : "batch")),
                          x3 ? (c->L[PN_L_FC_RB].wq ? "fc_gb:x3+fc_rb:n16" : "fc_gb:x3+fc_rb:fp32") : (c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch")), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
                          c->weights_were_cached ? "shared" : "own", nn_chains_of(c), nn_chains_of(c) > 1 ? ":" : "", nn_chains_of(c) > 1 ? c->chain_kind + 1 : "");
   if (w < 0 || (size_t)w >= n) return -1;
@@ -555,7 +564,7 @@ static uint16_t *shadow(pn_ctx *c, const float *p) {
       {c->c1ring, c->c1ringH, 5 * Bp * 128}, {c->c2ring, c->c2ringH, 3 * Bp * 512}, {c->c2out, c->c2outH, Bp * 512},
       {c->gru[0], c->gruH[0], 2 * Bp * 512}, {c->gru[1], c->gruH[1], 2 * Bp * 512}, {c->gru[2], c->gruH[2], 2 * Bp * 512},
       {c->gru[3], c->gruH[3], 2 * Bp * 512}, {c->rb, c->rbH, 2 * Bp * 128}};
-  for (auto &e : m) if (p >= e.f && p < e.f + e.n) return e.h + shadow_halfs_per_element(c) * (size_t)(p - e.f);
+  for (auto &e : m) if (p >= e.f && p < e.f + e.n) return e.h ? e.h + shadow_halfs_per_element(c) * (size_t)(p - e.f) : NULL;
   return NULL;
 }
 static PnSegs shadow_segs(pn_ctx *c, const PnSegs &A) {
@@ -575,6 +584,8 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
   // x3: the layers that run on the fp16 matrix cores from operand shadows — split precision (hi + lo planes) or fp16 operands (hi only)
   const bool x3 = c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16;
   const int np = c->nn_mode == PN_NN_MFMA_X3 ? 2 : 1;
+  const bool dm = c->direct != 0;   // the GRU steps take their activations straight from fragment-order fp32 shadows (pn_nn_d.hip): written by conv2
+                                    // (batch kernel, second output) and by the GRU steps themselves; every dense layer stays on the batch kernels
   const float *tab = c->tansig;
   int rc = 0;
   const int cur = (int)(t & 1), nxt = cur ^ 1;
@@ -598,6 +609,7 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 3;
     for (int j = 0; j < 3; j++) { A.p[j] = c->c2ring + (size_t)((t + 1 + j) % 3) * Bp * 512 + r0 * 512; A.ld[j] = 512; A.width[j] = 512; }
     if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c2out, 512, c->c2outH, 16, B, c->x3_rg, np);
+    else if (dm) rc |= pn_launch_dense(st, 0, A, NULL, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c2out, 512, B, 0, shadow(c, c2out), 16);   // + the shadow the GRUs read
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_CONV2].w, c->L[PN_L_CONV2].wp, c->L[PN_L_CONV2].bias, 512, c->geom[PN_L_CONV2].act, tab, c2out, 512, B, small); }
   const float *x = c2out;
   for (int i = 0; i < 4 && !rc; i++) {    // gru1 -> gru2 -> gru3 -> gru_gb, each fed the UPDATED state of its predecessor
@@ -606,6 +618,7 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
     float *ho = c->gru[i] + (size_t)cur * Bp * 512 + r0 * 512, *hn = c->gru[i] + (size_t)nxt * Bp * 512 + r0 * 512;
     PnSegs X = seg1(x, 512, 512);
     if (x3) rc |= pn_launch_gru_x3(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), B, c->x3_rg, np);
+    else if (dm) rc |= pn_launch_gru_d(st, shadow_segs(c, X), ho, shadow(c, ho), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, shadow(c, hn), B, c->x3_rg);
     else rc |= pn_launch_gru(st, strict, X, ho, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 512, c->geom[li].act, tab, hn, B, small_gru);
     x = hn;
   }
@@ -617,6 +630,7 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
     X.p[0] = g3; X.ld[0] = 512; X.width[0] = 512; X.p[1] = c2out; X.ld[1] = 512; X.width[1] = 512;
     const int li = PN_L_GRU_RB;
     if (x3) rc |= pn_launch_gru_x3(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), B, c->x3_rg, np);
+    else if (dm) rc |= pn_launch_gru_d(st, shadow_segs(c, X), rbo, shadow(c, rbo), c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, shadow(c, rbn), B, c->x3_rg);
     else rc |= pn_launch_gru(st, strict, X, rbo, c->L[li].w, c->L[li].rw, c->L[li].wp, c->L[li].rwp, c->L[li].bias, 128, c->geom[li].act, tab, rbn, B, small); }   // gru_rb (1024->128) crosses over with the dense layers
   { MaybeScope sc(c, KF_FC_GB, st);    // input = [conv2 out | gru1 | gru2 | gru3 | gru_gb] (rnn.cpp:72-77)
     PnSegs A; memset(&A, 0, sizeof(A)); A.n = 5;
@@ -689,7 +703,8 @@ static int launch_rnn(pn_ctx *c) {
   if (n <= 1) return launch_rnn_rows(c, 0, c->B, c->stream, c->small, c->small_gru);
   if (chain_streams_init(c, n)) return -1;
   // row ranges: equal shares rounded up to whole 128-row tiles; the last chain takes what is left
-  const size_t B = c->B, share = ((B + n - 1) / n + 127) / 128 * 128;
+  const size_t tile = c->direct ? 128 * (size_t)c->x3_rg : 128;            // rows per block of the family's kernels
+  const size_t B = c->B, share = ((B + n - 1) / n + tile - 1) / tile * tile;
   PN_HIP_CHECK(hipEventRecord(c->chain_fork, c->stream));                 // the front end's features (and last frame's state) are in place
   int rc = 0;
   for (int k = n - 1; k >= 0; k--) {                                      // the context's own stream last: the others are already queued
@@ -749,7 +764,7 @@ static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
   const int n16 = c->L[PN_L_FC_RB].wq != NULL;           // narrow layers on the 16x16x4 kernel (small batches; fc_rb in every MFMA mode, fc_gb in the fp32 one) or on the batch GEMM
-  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : 0, n16);
+  const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : (c->direct ? 10 + c->x3_rg : 0), n16);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;
   const int rows = 192;
@@ -761,7 +776,7 @@ static int nn_selftest(pn_ctx *c) {
   bool oom = false;
   for (int pass = 0; pass < 2 && !rc; pass++) {          // pass 0: the kernel family under test; pass 1: STRICT kernels
     g_last_alloc_oom = false;
-    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru, c->x3_rg, n16);
+    cx[pass] = ctx_create(m, c->device, rows, pass ? PN_NN_STRICT : c->nn_mode, NULL, false, c->small, c->small_gru, c->x3_rg, n16, pass ? 0 : c->direct);
     if (!cx[pass]) { rc = -1; oom = g_last_alloc_oom; break; }
     unsigned x = 12345u;
     for (int step = 0; step < 2 && !rc; step++) {
@@ -982,7 +997,7 @@ static int process_active(pn_ctx *c, const void *d_in, void *d_out, float *d_gr,
   a.hist = c->hist; a.yring = c->yring; a.eyring = c->eyring; a.c1ring = c->c1ring; a.c2ring = c->c2ring; a.rb = c->rb;
   for (int i = 0; i < 4; i++) { a.gru[i] = c->gru[i]; a.gruH[i] = (uint4 *)c->gruH[i]; }
   a.c1ringH = (uint4 *)c->c1ringH; a.c2ringH = (uint4 *)c->c2ringH; a.rbH = (uint4 *)c->rbH;
-  a.np = c->c1ringH ? (int)shadow_halfs_per_element(c) : 0;
+  a.np = c->c2outH ? (int)shadow_halfs_per_element(c) : 0;     // (a NULL shadow is skipped)
   a.B = B; a.Bp = (long long)c->Bp; a.t = c->t; a.tn = c->tn;
   pn_launch_inactive_save(c->stream, a, ni);
   if (process_dev(c, d_in, d_out, d_gr, is_i16)) {
@@ -1297,6 +1312,7 @@ static int rnn_state_copy(pn_ctx *c, bool to_device, float *conv1, float *conv2,
   auto resplit = [&](float *dev, int width) {
     if (x3) split_rc |= pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 2);
     if (f16) split_rc |= pn_launch_split_x3(c->stream, dev, width, width, shadow(c, dev), (int)Bp, 1);
+    if (c->direct && to_device && shadow(c, dev)) split_rc |= pn_launch_split_d(c->stream, dev, width, width, shadow(c, dev), (int)Bp);   // (GRU states; the conv FIFOs have no shadow there)
   };
   if (conv1) for (int j = 0; j < 4; j++) {
     float *d = c->c1ring + (size_t)((t + 1 + j) % 5) * Bp * 128;

@@ -77,6 +77,15 @@ int pn_x3_rg_for(int n_rows);
 int pn_x3_sat_set(int enable);          // debug counter of operand values clamped to +-65504 (current device): reset + switch
 long long pn_x3_sat_read();             // ... and its value, or -1
 int pn_launch_split_x3(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows_padded, int np);
+// direct-operand fp32 GRU kernels (pn_nn_d.hip): the large-batch GRU steps of nn_mode PN_NN_MFMA.  X panels / h_oldS / h_newS are the
+// uint4* fragment-order fp32 shadows (carried as float* in PnSegs), Wp / Up the fp32 packed tiles of pn_pack_weights; bit-identical
+// to pn_launch_gru.  rg: row groups of 32 per wave (1 | 2)
+int pn_launch_gru_d(hipStream_t st, const PnSegs &X, const float *h_old, const void *h_oldS, const float *Wp,
+                    const float *Up, const float *b, int N, int act, const float *tansig, float *h_new, void *h_newS,
+                    int n_rows, int rg);
+int pn_launch_split_d(hipStream_t st, const float *src, int ld, int width, void *S, int n_rows);
+int pn_direct_for(int n_rows);          // 1: a PN_NN_MFMA context of this many streams runs the direct-operand family (PERCEPNET_NN_DIRECT overrides)
+int pn_direct_rg_for(int n_rows);       // its rows per wave / 32 (PERCEPNET_NN_DIRECT_RG overrides)
 // narrow layers (N <= 48) of small-batch contexts: 16x16x4 MFMA tiles, one wave per (16 rows, 16 columns) (pn_nn_small.hip)
 size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);
@@ -89,8 +98,9 @@ int pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const 
 // pn_small_rows(): the batch size up to which a context picks the small family (PERCEPNET_SMALL_ROWS, default 4096).
 int pn_small_rows();
 int pn_small_gru_rows();
+// outS (optional, batch kernels only): fragment-order fp32 shadow of `out`, a buffer nts_out column tiles wide (pn_nn_common.h)
 int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
-                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small);
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small, void *outS = nullptr, int nts_out = 0);
 int pn_launch_gru(hipStream_t st, int strict, const PnSegs &X, const float *h_old, const float *W, const float *U,
                    const float *Wp, const float *Up, const float *b, int N, int act, const float *tansig,
                    float *h_new, int n_rows, int small);

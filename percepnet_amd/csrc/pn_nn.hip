@@ -447,11 +447,14 @@ __global__ __launch_bounds__(NN_THREADS) void pn_gru_mfma_p_kernel(
     _Pragma("unroll") for (int t_ = 0; t_ < NT; t_++)                                                      \
       acc[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[QQ].c, (o).b[t_][QQ].c, acc[t_], 0, 0, 0);      \
     PN_SB(); } while (0)
-template <int NT>
-__global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
-    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
-    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
-  __shared__ NnShared S;
+// SH: the layer also feeds the direct-operand GRU kernels (pn_nn_d.hip) — its output leaves through the wave's LDS stage as fp32 rows AND
+// as the fragment-order shadow outS (a template parameter, not a run-time branch: the extra epilogue must not cost the plain
+// instantiation its second wave per SIMD — it did: 192 -> 202 registers)
+template <int NT, bool SH>
+__device__ __forceinline__ void pn_dense_mfma_p_body(
+    NnShared &S, const PnSegs &A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks,
+    uint4 *__restrict__ outS, int nts_out) {
 #ifdef PN_NN_SETPRIO
   __builtin_amdgcn_s_setprio(PN_NN_SETPRIO);   // experiment: the MFMA waves win every issue arbitration against co-resident DSP waves
 #endif
@@ -533,6 +536,20 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
 #undef DP_STOREB
 #undef DP_LOADB
 #undef DP_SEL
+  if constexpr (SH) {
+    // (the operand buffers are dead: every wave has passed the last interval's barrier)
+    float *T = &S.A[0][0][0] + wave * 32 * PN_TLD;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int ct = cb * NT + t;
+      if (ct * 32 >= N) break;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = pn_act(acc[t][i], act, S.tansig);
+      pn_store_tile_frag(T, v, out, ldo, ct * 32, N, m0 + 32 * wave, n_rows, outS + ((size_t)mt * nts_out + ct) * PN_SHADOW_CHUNK, 32 * wave, lane);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const int col = (cb * NT + t) * 32 + (lane & 31);
@@ -542,6 +559,23 @@ __global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
       if (row < n_rows && col < N) out[(size_t)row * ldo + col] = pn_act(acc[t][i], act, S.tansig);
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NN_THREADS) void pn_dense_mfma_p_kernel(
+    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks) {
+  __shared__ NnShared S;
+  pn_dense_mfma_p_body<NT, false>(S, A, Wp, bias, N, KT, tps, act, tansig, out, ldo, n_rows, n_mtiles, n_cblocks, nullptr, 0);
+}
+// the same with the shadow output (conv2 of a context whose GRU steps run on pn_nn_d.hip); two waves per SIMD asked for explicitly
+template <int NT>
+__global__ __launch_bounds__(NN_THREADS, 2) void pn_dense_mfma_ps_kernel(
+    PnSegs A, const float *__restrict__ Wp, const float *__restrict__ bias, int N, int KT, int tps, int act,
+    const float *__restrict__ tansig, float *__restrict__ out, int ldo, int n_rows, int n_mtiles, int n_cblocks,
+    uint4 *__restrict__ outS, int nts_out) {
+  __shared__ NnShared S;
+  pn_dense_mfma_p_body<NT, true>(S, A, Wp, bias, N, KT, tps, act, tansig, out, ldo, n_rows, n_mtiles, n_cblocks, outS, nts_out);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -564,7 +598,9 @@ int pn_launch_dense_small(hipStream_t st, const PnSegs &A, const float *Wp, cons
 int pn_launch_gru_small(hipStream_t st, const PnSegs &X, const float *h_old, const float *Wp, const float *Up,
                         const float *b, int N, int act, const float *tansig, float *h_new, int n_rows);
 int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W, const float *Wp, const float *bias,
-                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small) {
+                     int N, int act, const float *tansig, float *out, int ldo, int n_rows, int small, void *outS, int nts_out) {
+  // outS: fragment-order fp32 shadow of `out` (a buffer nts_out column tiles wide) for the direct-operand GRU kernels — batch kernels only
+  if (outS && (strict || small)) { pn_set_error("pn_launch_dense: a shadow output needs the batch-GEMM kernels"); return -1; }
   if (strict) {
     const int nbx = (N + 63) / 64;
     hipLaunchKernelGGL(pn_dense_strict_kernel, dim3((unsigned)nbx * (unsigned)n_rows), dim3(64), 0, st, A, W, bias, N, act, tansig, out, ldo, nbx);
@@ -581,7 +617,11 @@ int pn_launch_dense(hipStream_t st, int strict, const PnSegs &A, const float *W,
   const int n_cblocks = pn_ct_padded(N, NT) / NT;
   const int n_mtiles = (n_rows + BM - 1) / BM;
   const int grid = 8 * ((n_mtiles + 7) / 8) * n_cblocks;
-  if (NT == 4)
+  if (outS) {
+    if (NT != 4) { pn_set_error("pn_launch_dense: a shadow output needs whole 128-column blocks"); return -1; }
+    hipLaunchKernelGGL(pn_dense_mfma_ps_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
+                       tansig, out, ldo, n_rows, n_mtiles, n_cblocks, (uint4 *)outS, nts_out);
+  } else if (NT == 4)
     hipLaunchKernelGGL(pn_dense_mfma_p_kernel<4>, dim3(grid), dim3(NN_THREADS), 0, st, A, Wp, bias, N, KT, tps, act,
                        tansig, out, ldo, n_rows, n_mtiles, n_cblocks);
   else

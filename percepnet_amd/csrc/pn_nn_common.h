@@ -134,6 +134,60 @@ __device__ __forceinline__ void pn_gru_epilogue(const floatx16 *acc, const float
   }
 }
 
+// ---- fragment-order fp32 shadows (direct-operand GRU kernels, pn_nn_d.hip) --------------------------------------------------
+//   shadow[M tile of 128][column tile of 32][q 0..3][kh 0..1][row 0..127][4 floats: k = 32 ct + 8 q + 2 s + kh, s = 0..3]
+// = 8 slabs (j = 2q + kh) of 128 sixteen-byte entries per (M tile, column tile): lane (row r, k-half kh) of a consumer wave
+// loads entry (j, r) = its operand of four consecutive v_mfma_f32_32x32x2_f32 k-steps.
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+#define PN_SHADOW_CHUNK 1024           // uint4 per (M tile of 128, column tile)
+#define PN_TLD 36                      // epilogue stage: 32 rows x 32 columns per wave, rows padded to 36 floats
+// Stores one 32 x 32 output tile of a wave (v[i] = value of row (i&3) + 8(i>>2) + 4(lane>>5), column lane&31) through
+// the wave's private LDS stage, kept in FRAGMENT column order (column c = 8q + 2s + kh at 8q + 4kh + s): one
+// ds_read_b128 is a slab entry.  fp32 rows go out as 32-byte runs (4 lanes = one 128-byte row segment; out may be
+// null), the shadow as 16-byte entries, 32 consecutive rows of a slab = 512 contiguous bytes (S may be null; srow0 = first
+// row within the M tile of 128).  Rows at or past n_rows are not stored anywhere.
+__device__ __forceinline__ void pn_store_tile_frag(float *T, const float (&v)[16], float *__restrict__ out, int ldo, int col0,
+                                             int n_cols, int grow0, int n_rows, uint4 *__restrict__ S, int srow0, int lane) {
+  {
+    const int c = lane & 31, pc = (c & 24) + 4 * (c & 1) + ((c >> 1) & 3);
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * PN_TLD + pc] = v[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (out) {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const int idx = lane + 64 * p, row = idx >> 2, q = idx & 3;
+      const fvec4 e = *reinterpret_cast<const fvec4 *>(&T[row * PN_TLD + 8 * q]);        // kh = 0: columns 8q + 0, 2, 4, 6
+      const fvec4 o = *reinterpret_cast<const fvec4 *>(&T[row * PN_TLD + 8 * q + 4]);    // kh = 1: columns 8q + 1, 3, 5, 7
+      if (grow0 + row < n_rows) {
+        float *dst = out + (size_t)(grow0 + row) * ldo + col0 + 8 * q;
+        if (col0 + 32 <= n_cols && (ldo & 3) == 0) {
+          *reinterpret_cast<fvec4 *>(dst) = fvec4{e.x, o.x, e.y, o.y};
+          *reinterpret_cast<fvec4 *>(dst + 4) = fvec4{e.z, o.z, e.w, o.w};
+        } else {
+          const float f[8] = {e.x, o.x, e.y, o.y, e.z, o.z, e.w, o.w};
+#pragma unroll
+          for (int j = 0; j < 8; j++) if (col0 + 8 * q + j < n_cols) dst[j] = f[j];
+        }
+      }
+    }
+  }
+  if (S) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int j = 2 * p + (lane >> 5), row = lane & 31;                                // slab j = 2q + kh
+      // (row-guarded like the fp32 rows: with row-range chains the rows past n_rows belong to another chain's launches)
+      if (grow0 + row < n_rows) S[j * 128 + srow0 + row] = *reinterpret_cast<const uint4 *>(&T[row * PN_TLD + 4 * j]);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                      // the stage is reused by the next tile of this wave
+}
+
+
 // MFMA result hazard: a VALU / VMEM read of a register written by v_mfma_f32_32x32x2_f32 needs 18 wait
 // states after the MFMA on gfx950 — measured (tools/probes/mfma_waitstate_probe.hip: 17 states still return the old
 // value in every lane, 18 never do) — and that is exactly what hipcc's hazard recogniser inserts, also across a loop
