@@ -234,19 +234,24 @@ def gru_roofline(kt, B, fp16, desc, n_gpus=1, fps=None, traffic_tag=""):
     flops = rows * GRU512_FLOP_PER_STREAM_FRAME
     x3 = desc.get("nn") == "mfma_x3"
     # the fp16-operand mode runs the hi-plane-only instantiation of the split-precision kernels (pn_nn_x3.hip)
-    kname = "pn_gru_x3_kernel" if (x3 or fp16) else ("pn_gru_small_kernel" if desc.get("gru") == "small" else "pn_gru_mfma_p_kernel")
+    direct = str(desc.get("gru", "")).startswith("direct")     # round 6: A fragments straight from fragment-order fp32 shadows (pn_nn_d.hip)
+    kname = "pn_gru_x3_kernel" if (x3 or fp16) else ("pn_gru_small_kernel" if desc.get("gru") == "small" else
+                                                      ("pn_gru_d_kernel" if direct else "pn_gru_mfma_p_kernel"))
     traffic, traffic_src = pmc_traffic_bytes(B, kname[:11], traffic_tag)
     ach = chains * flops / avg_s / 1e12
     # dense fp16 / fp32 MFMA peaks (MI355X_MICROARCH.md).  Split precision: `achieved` stays the ALGORITHMIC rate (2 M N K per
     # launch); every product costs three fp16 MFMAs, so the bound is a third of the dense fp16 peak
     peak = round(2500.0 / 3, 1) if x3 else (2500.0 if fp16 else PEAK_FP32_MFMA_TFLOPS)
-    alg_launch = int(3 * rows * 512 * (2 if fp16 else 4) + (rows * 512 * 4 if (fp16 or x3) else 0) + 2 * 512 * 1536 * (2 if fp16 else 4))
+    # x, h_old, h_new once each (+ the fp32 state read for the blend in the shadow-operand modes) + the weights; the direct-operand
+    # kernel reads x and h_old as shadows, h_old again as rows for the blend, and writes h_new as rows AND as shadow: 5 arrays
+    alg_launch = int((5 if direct else 3) * rows * 512 * (2 if fp16 else 4) + (rows * 512 * 4 if (fp16 or x3) else 0) + 2 * 512 * 1536 * (2 if fp16 else 4))
     r = {"kernel": kname + ("<rows/32, planes=1>" if fp16 else ("<rows/32, planes=2>" if x3 else "")) +
                    f" (512->512 reset-after GRU step, 4 layers per frame x {chains} launch(es) per layer)",
          "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": None if traffic is None else traffic * chains,
          "traffic_source": traffic_src, "kernels_snapshot": kernels_snapshot(),
          "algorithmic_bytes_per_launch": alg_launch * chains,
+         **({"operands": "A fragments from fragment-order fp32 shadows, 64 rows per wave (pn_nn_d.hip), bit-identical to the batch-GEMM family"} if direct else {}),
          "flop_per_launch": int(flops), "avg_launch_ms": round(avg_s * 1e3, 4), "concurrent_launches": chains,
          "rows_per_launch": int(rows)}
     if chains > 1:

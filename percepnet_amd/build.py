@@ -20,7 +20,7 @@ RUN = os.path.join(LIBDIR, "percepnet_run")
 EXPORT_MAP = os.path.join(CSRC, "libpercepnet_hip.map")    # ld version script: the export list (everything else is local)
 RELINKED = os.path.join(LIBDIR, "percepNet_run_relinked")    # reference src/main.cpp, untouched, linked against LIB
 REFERENCE_SRC = os.environ.get("PERCEPNET_REFERENCE_SRC", "/root/reference/src")
-SOURCES = ["pn_tables.cpp", "pn_model.cpp", "pn_pack.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_nn_d.hip", "pn_targets.hip", "pn_state.hip", "pn_active.hip", "pn_context.cpp",
+SOURCES = ["pn_tables.cpp", "pn_model.cpp", "pn_pack.cpp", "pn_dsp_fe.hip", "pn_dsp_fe_g2.hip", "pn_dsp_fe_split_s.hip", "pn_dsp_fe_split_p.hip", "pn_dsp.hip", "pn_nn.hip", "pn_nn_small.hip", "pn_nn_x3.hip", "pn_nn_d.hip", "pn_nn_n48.hip", "pn_targets.hip", "pn_state.hip", "pn_active.hip", "pn_context.cpp",
            "pn_featgen.cpp", "rnnoise_compat.cpp"]
 # percepnet_run.cpp / percepnet_featgen.cpp (the CLIs) are linked separately against the library
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",

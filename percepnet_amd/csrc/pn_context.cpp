@@ -53,6 +53,7 @@ struct pn_ctx {
   int device, B, nn_mode;
   int x3_rg;                       // split-precision mode: row groups of 32 per wave (1: 128-row blocks, 2: 256-row blocks), fixed at creation from B
   int small, small_gru;            // network kernel family per layer kind: 1 = small-batch (pn_nn_small.hip), fixed at creation from B
+  int n48;                         // fp32 MFMA mode, batches above the n16 limit: fc_gb on the batch form of the 16x16x4 kernel (pn_nn_n48.hip)
   int direct;                      // fp32 MFMA mode, large batches: 1 = the direct-operand family (pn_nn_d.hip: A fragments from fp32 shadows,
                                    // 64 rows per wave when x3_rg == 2); fixed at creation from B, never together with small / small_gru
   int fe_mode;                     // front end: FE_SPLIT = three phase kernels (pn_dsp_fe_split_*.hip); FE_MONO_G4 / FE_MONO_G2 = the
@@ -197,6 +198,10 @@ static int pn_fe_mode_for(int n_streams) {
 // narrow (34-column) dense layers on 16x16x4 MFMA tiles (pn_dense_n16_kernel) up to this batch size (measured: fc_gb 0.026 vs
 // 0.056 ms at 1024 streams, 0.082 vs 0.101 at 16384, 0.327 vs 0.180 at 65536 where the batch GEMM's operand reuse wins);
 // PERCEPNET_N16_ROWS overrides
+static bool n48_enabled() {             // PERCEPNET_N48=0: fc_gb of large fp32 contexts back on the 32-column batch GEMM
+  const char *e = getenv("PERCEPNET_N48");
+  return !e || atoi(e) != 0;
+}
 static bool n16_rows_ok(int n_streams) {
   const char *e = getenv("PERCEPNET_N16_ROWS");
   return n_streams <= (e ? atoi(e) : 20480);
@@ -242,7 +247,7 @@ extern "C" pn_ctx *pn_ctx_create(const pn_model *model, int device, int n_stream
 
 // Biases + weights of `model` on the context's device in the layout `nn_mode` reads: STRICT the nnet_data.h arrays as they
 // are, the MFMA modes re-packed tile orders (pn_pack.cpp, pn_nn_x3.hip).  Returns NULL (pn_set_error) on failure.
-static SharedWeights *build_weights(pn_ctx *c, const pn_model *model, int nn_mode, bool n16) {
+static SharedWeights *build_weights(pn_ctx *c, const pn_model *model, int nn_mode, bool n16, bool n48) {
   SharedWeights *w = new SharedWeights();
   memset(w->L, 0, sizeof(w->L));
   for (int li = 0; li < PN_NLAYERS; li++) {
@@ -275,7 +280,7 @@ static SharedWeights *build_weights(pn_ctx *c, const pn_model *model, int nn_mod
         pn_pack_weights(H.w, K, k_alloc, ncols, ctr, packed.data());
         if (upload_w(c, w, &w->L[li].wp, packed.data(), packed.size())) goto fail_w;
         if (hipStreamSynchronize(c->stream) != hipSuccess) goto fail_w;   // `packed` dies at scope end
-        if (n16 && H.kind == PN_KIND_DENSE && ncols <= 48 && K % 128 == 0) {     // fc_gb, fc_rb
+        if ((n16 || (n48 && li == PN_L_FC_GB)) && H.kind == PN_KIND_DENSE && ncols <= 48 && K % 128 == 0) {     // fc_gb, fc_rb (n48: fc_gb only)
           std::vector<float> pq(pn_packed_floats_n16(K, ncols));
           pn_pack_weights_n16(H.w, K, ncols, pq.data());
           if (upload_w(c, w, &w->L[li].wq, pq.data(), pq.size())) goto fail_w;
@@ -370,10 +375,13 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
   for (int li = 0; li < PN_NLAYERS; li++) { c->geom[li] = model->L[li]; c->geom[li].bias = c->geom[li].w = c->geom[li].rw = NULL; }
   {   // the device copy of the weights: shared with every other context of this model content on this device in this mode
     // narrow layers on the 16x16x4 kernel at small batches in every MFMA mode (in the shadow-operand modes that is fc_rb; fc_gb runs on their own kernels)
-    const bool n16 = (nn_mode != PN_NN_STRICT) && (force_n16 >= 0 ? force_n16 != 0 : n16_rows_ok(n_streams));
+    // force_n16 (the self-tests' temporary contexts): 0 batch GEMM, 1 n16, 2 n48
+    const bool n16 = (nn_mode != PN_NN_STRICT) && (force_n16 >= 0 ? force_n16 == 1 : n16_rows_ok(n_streams));
+    const bool n48 = nn_mode == PN_NN_MFMA && !c->small && !n16 && (force_n16 >= 0 ? force_n16 == 2 : n48_enabled());
+    c->n48 = n48;
     std::array<unsigned char, 32> dig;
     memcpy(dig.data(), model->sha256, 32);
-    c->weights_key = std::make_tuple(dig, model->n_floats, device, nn_mode, n16 ? 1 : 0);
+    c->weights_key = std::make_tuple(dig, model->n_floats, device, nn_mode, n16 ? 1 : (n48 ? 2 : 0));
     std::lock_guard<std::mutex> build_lk(g_weights_build_mu[device & 15]);   // one build per device at a time; the map lock is never held across a build
     SharedWeights *hit = NULL;
     {
@@ -383,7 +391,7 @@ static pn_ctx *ctx_create(const pn_model *model, int device, int n_streams, int 
     }
     if (hit) { c->weights = hit; c->weights_were_cached = true; }
     else {
-      SharedWeights *w = build_weights(c, model, nn_mode, n16);
+      SharedWeights *w = build_weights(c, model, nn_mode, n16, n48);
       if (!w) goto fail;
       w->refs = 1;
       c->weights = w;
@@ -485,7 +493,7 @@ extern "C" int pn_ctx_describe(const pn_ctx *c, char *buf, size_t n) {
   const char *dk = c->x3_rg >= 2 ? "direct_rows64" : "direct_rows32";      // direct-operand fp32 GRU kernels (pn_nn_d.hip); the dense layers stay "batch"
   const int w = snprintf(buf, n, "nn=%s dense=%s gru=%s gru_rb=%s narrow=%s frontend=%s weights=%s nn_chains=%d%s%s", nn, x3 ? xk : (fam && c->small ? "small" : "batch"),
                          x3 ? xg : (c->direct ? dk : (fam && c->small_gru ? "small" : "batch")), x3 ? xg : (c->direct ? dk : (fam && c->small ? "small" : "batch")),
-                         x3 ? (c->L[PN_L_FC_RB].wq ? "fc_gb:x3+fc_rb:n16" : "fc_gb:x3+fc_rb:fp32") : (c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch")), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
+                         x3 ? (c->L[PN_L_FC_RB].wq ? "fc_gb:x3+fc_rb:n16" : "fc_gb:x3+fc_rb:fp32") : (c->n48 ? "fc_gb:n48+fc_rb:batch" : (c->L[PN_L_FC_GB].wq ? "n16" : (fam && c->small ? "small" : "batch"))), c->fe_mode == FE_SPLIT ? "split" : (c->fe_mode == FE_MONO_G2 ? "g2" : "g4"),
                          c->weights_were_cached ? "shared" : "own", nn_chains_of(c), nn_chains_of(c) > 1 ? ":" : "", nn_chains_of(c) > 1 ? c->chain_kind + 1 : "");
   if (w < 0 || (size_t)w >= n) return -1;
   if (c->x3_sat) {                                        // debug: operand values clamped to +-65504 so far (device-wide counter)
@@ -637,6 +645,7 @@ static int launch_rnn_rows(pn_ctx *c, size_t r0, size_t nrows, hipStream_t st, i
     const float *ps[5] = {c2out, g1, g2, g3, gb};
     for (int j = 0; j < 5; j++) { A.p[j] = ps[j]; A.ld[j] = 512; A.width[j] = 512; }
     if (x3) rc |= pn_launch_dense_x3(st, shadow_segs(c, A), c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, NULL, 0, B, c->x3_rg, np);
+    else if (c->n48) rc |= pn_launch_dense_n48(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, B);
     else if (c->L[PN_L_FC_GB].wq) rc |= pn_launch_dense_n16(st, A, c->L[PN_L_FC_GB].wq, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, B);
     else rc |= pn_launch_dense(st, strict, A, c->L[PN_L_FC_GB].w, c->L[PN_L_FC_GB].wp, c->L[PN_L_FC_GB].bias, 34, c->geom[PN_L_FC_GB].act, tab, gr, 68, B, small); }
   { MaybeScope sc(c, KF_FC_RB, st);
@@ -763,7 +772,7 @@ static pn_model *selftest_model() {
 static int nn_selftest(pn_ctx *c) {
   const char *env = getenv("PERCEPNET_SELFTEST");
   if (env && !atoi(env)) return 0;
-  const int n16 = c->L[PN_L_FC_RB].wq != NULL;           // narrow layers on the 16x16x4 kernel (small batches; fc_rb in every MFMA mode, fc_gb in the fp32 one) or on the batch GEMM
+  const int n16 = c->n48 ? 2 : (c->L[PN_L_FC_RB].wq != NULL);   // narrow layers: 1 = the 16x16x4 kernel (small batches; fc_rb in every MFMA mode, fc_gb in the fp32 one), 2 = fc_gb on its batch form, 0 = the batch GEMM
   const auto key = std::make_tuple(c->device, c->nn_mode, c->small, c->small_gru, (c->nn_mode == PN_NN_MFMA_X3 || c->nn_mode == PN_NN_MFMA_F16) ? c->x3_rg : (c->direct ? 10 + c->x3_rg : 0), n16);
   std::lock_guard<std::mutex> lk(g_selftest_mu);
   if (g_selftest_done.count(key)) return 0;

@@ -91,6 +91,9 @@ size_t pn_packed_floats_n16(int K, int ncols);
 void pn_pack_weights_n16(const float *W, int K, int ncols, float *Wq);
 int pn_launch_dense_n16(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
                          const float *tansig, float *out, int ldo, int n_rows);
+// the batch form for large batches (pn_nn_n48.hip): 128-row blocks x 48 columns of 16x16x4 tiles, the same packed weights Wq
+int pn_launch_dense_n48(hipStream_t st, const PnSegs &A, const float *Wq, const float *bias, int N, int act,
+                        const float *tansig, float *out, int ldo, int n_rows);
 // The network launchers return 0, or -1 (pn_set_error) WITHOUT launching when they refuse a geometry: the caller fails
 // the frame (launch_rnn -> pn_process_*), it must never report a frame whose layer outputs are stale.
 // pn_check_dense_geometry / pn_check_gru_geometry (pn_launch_check.h) are the HIP-free predicates behind the refusals.

@@ -214,10 +214,12 @@ __global__ __launch_bounds__(256) void pn_split_d_kernel(const float *__restrict
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
-// Which PN_NN_MFMA contexts run this family (read at every context creation; tests switch it between contexts):
-// PERCEPNET_NN_DIRECT=0|1 overrides the batch-size rule.
+// Which PN_NN_MFMA contexts run their GRU steps here (read at every context creation; tests switch it between contexts):
+// PERCEPNET_NN_DIRECT=0|1 overrides the batch-size rule.  Measured against the batch family, same box, default chain rule
+// (profiles/r06_direct_operand_gru.log): frame time -0.6 % at 24 576 streams, -1.1 % at 32 768, -1.2 % at 61 440 / 66 560, -1.4 % at
+// 69 632 (the 512 -> 512 step at 65 536: 1.552 -> 1.523 ms), even at 16 384, +1.4 % at 8192 (too few blocks per launch).
 #ifndef PN_DIRECT_ROWS
-#define PN_DIRECT_ROWS 0x7fffffff      // default: off until measured
+#define PN_DIRECT_ROWS 24576
 #endif
 int pn_direct_for(int n_rows) {
   const char *e = getenv("PERCEPNET_NN_DIRECT");

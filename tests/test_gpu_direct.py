@@ -131,3 +131,30 @@ def test_direct_family_shadows_follow_every_state_change(model, monkeypatch):
     for i, (a, b) in enumerate(zip(runs[False], runs[True])):
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), i
+
+
+@pytest.mark.parametrize("B", [300, 128 * 5 + 1])
+def test_fc_gb_on_16x16x4_batch_tiles_is_bit_identical(model, oracle, monkeypatch, B):
+    """fc_gb (2560 -> 34, reference rnn.cpp:72-77) of large fp32 contexts runs on 48-column blocks of v_mfma_f32_16x16x4_f32 tiles
+    (pn_nn_n48.hip) instead of two padded 32-column tiles: the same k-ascending chain, so g (and with it the PCM) must not
+    change by a bit — ragged batches, five frames into every ring, and as two row-range chains."""
+    monkeypatch.setenv("PERCEPNET_SMALL_ROWS", "0")
+    monkeypatch.setenv("PERCEPNET_N16_ROWS", "0")                   # not the latency-regime kernel either
+    monkeypatch.setenv("PERCEPNET_NN_DIRECT", "0")
+    T = 8
+    pcm = synth.synth_batch(B, T, first_stream=7)
+    feat = np.random.default_rng(9).standard_normal((B, 70)).astype(np.float32)
+    res = {}
+    for n48 in ("0", "1"):
+        monkeypatch.setenv("PERCEPNET_N48", n48)
+        ctx = api.Context(model, B, nn_mode=api.NN_MFMA)
+        assert ctx.describe()["narrow"] == ("fc_gb:n48+fc_rb:batch" if n48 == "1" else "batch"), ctx.describe()
+        o, g = ctx.run_pcm(pcm)
+        res[n48] = (o, g, ctx.compute_rnn(feat))
+        ctx.close()
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1].view(np.uint32), res["1"][1].view(np.uint32))
+    assert np.array_equal(res["0"][2].view(np.uint32), res["1"][2].view(np.uint32))
+    ro, rg = oracle.run_pcm(pcm[B - 1])
+    assert np.abs(res["1"][0][B - 1].astype(np.int32) - ro.astype(np.int32)).max() <= PCM_TOL_LSB
+    assert np.abs(res["1"][1][B - 1] - rg).max() <= GR_TOL
