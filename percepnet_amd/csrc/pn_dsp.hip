@@ -100,34 +100,41 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
     }
     // pitch_filter (436-485, skipped when silent, 536-538), gain (539-544), then the Hermitian extension + 1/960 of
     // inverse_transform (306-317).  Input i of the transform is bin k = i (i <= 480) or 960 - i (conjugated); bins >= 400
-    // are exactly 0 (interp_band_gain never writes them).  Lane l < 60, butterfly c, input j: i = 4l + c + 240j.
+    // are exactly 0 (interp_band_gain never writes them).
+    // Round 6: in two phases.  (A) every lane takes PAIRS of bins (one coalesced 16-byte load per spectrum: 4 + 4 load
+    // instructions per stream, each bin's filter / gain arithmetic done once) and parks 1/960 of the result in the first 3200
+    // bytes of the FFT buffer; (B) lane l < 60 collects the 16 inputs 4l + c + 240j of its four first-stage butterflies from
+    // there (mirrored inputs: imaginary part negated, which commutes with the scaling bit for bit; absent bins: +0 / -0 as
+    // before).  Until round 5 every INPUT was fetched and filtered separately: 32 strided 8-byte loads per lane whose lines
+    // the CU's 16 waves evicted from L1 between the four butterflies, and each bin's arithmetic done twice.
     // (round 5: a two-register-set software pipeline over the four butterflies — the spectra of c + 1 requested before the
     // arithmetic of c — unrolls to 27 spilled registers at four waves per SIMD: 0.296 vs 0.250 ms, profiles/r05_front_end_variants.log)
-    if (lane < 60) {
-      const float2 *Xs = Xspec + (size_t)s * PN_SPEC_BINS, *Ps = Pspec + (size_t)s * PN_SPEC_BINS;
-#pragma unroll 1
-      for (int c = 0; c < 4; c++) {
-        float2 xv[4], pv[4];
-        int kk[4];
+    {
+      const float4 *X4 = reinterpret_cast<const float4 *>(Xspec + (size_t)s * PN_SPEC_BINS);
+      const float4 *P4 = reinterpret_cast<const float4 *>(Pspec + (size_t)s * PN_SPEC_BINS);
+      float4 xq[4], pq[4];
+      int la = lane;
+      asm volatile("" : "+v"(la));                          // (opaque, as lq below)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int i = 4 * lc + c + 240 * j;
-          kk[j] = (i <= PN_FRAME) ? i : PN_WINDOW - i;
-          const int kc = kk[j] < PN_SPEC_BINS ? kk[j] : PN_SPEC_BINS - 1;
-          xv[j] = Xs[kc];
-          pv[j] = Ps[kc];
-        }
-        float2 f[4];
+      for (int it = 0; it < 4; it++) {
+        const int m = la + 64 * it, mc = m < PN_SPEC_BINS / 2 ? m : PN_SPEC_BINS / 2 - 1;
+        xq[it] = X4[mc];
+        pq[it] = sil ? make_float4(0.f, 0.f, 0.f, 0.f) : P4[mc];
+      }
+      float4 *Y4 = reinterpret_cast<float4 *>(W.fft);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int i = 4 * lc + c + 240 * j;
-          float2 x = make_float2(0.f, 0.f);
-          if (kk[j] < PN_SPEC_BINS) {
-            x = xv[j];
-            const int b = SH.band[kk[j]];
-            const float fr = SH.frac[kk[j]];
+      for (int it = 0; it < 4; it++) {
+        const int m = la + 64 * it;
+        if (m < PN_SPEC_BINS / 2) {
+          float2 y[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int k = 2 * m + h;
+            float2 x = h ? make_float2(xq[it].z, xq[it].w) : make_float2(xq[it].x, xq[it].y);
+            const int b = SH.band[k];
+            const float fr = SH.frac[k];
             if (!sil) {
-              const float2 p = pv[j];
+              const float2 p = h ? make_float2(pq[it].z, pq[it].w) : make_float2(pq[it].x, pq[it].y);
               const float rf1 = (1 - fr) * W.e[2][b] + fr * W.e[2][b + 1];
               x.x = rf1 * x.x; x.y = rf1 * x.y;
               const float rf2 = (1 - fr) * W.e[1][b] + fr * W.e[1][b + 1];
@@ -135,17 +142,44 @@ __global__ __launch_bounds__(DSP_THREADS, PN_DSP_WAVES_PER_SIMD) void pn_backend
             }
             const float gf = (1 - fr) * W.e[0][b] + fr * W.e[0][b + 1];
             x.x *= gf; x.y *= gf;
+            y[h] = make_float2(scale * x.x, scale * x.y);
           }
-          if (i > PN_FRAME) x.y = -x.y;
-          f[j] = make_float2(scale * x.x, scale * x.y);
+          Y4[m] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
         }
-        fs_bfly4_m1(f);
-        const int off = c == 0 ? Z.p1off[0] : (c == 1 ? Z.p1off[1] : (c == 2 ? Z.p1off[2] : Z.p1off[3]));
-        float4 *dst = reinterpret_cast<float4 *>(W.fft + off);
-        dst[0] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
-        dst[1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
       }
     }
+    PN_WAVE_SYNC();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float2 fin[4][4];                                     // [butterfly c][input j]
+      // input i = 4l + c + 240j: bin i for j < 2, bin 960 - i (conjugated) for j >= 2 — except i = 480 itself (l = c = 0, j = 2:
+      // its own mirror, not conjugated).  Two base addresses + immediates; a bin index past 399 (up to 480) reads stale bytes
+      // of the FFT buffer that the select below replaces by the reference's exact zero
+      int lq = lc;
+      asm volatile("" : "+v"(lq));                          // opaque: the lane's addresses and masks are rebuilt per stream, not hoisted and spilled
+      const float2 *Yd = W.fft + 4 * lq, *Ym = W.fft + (PN_WINDOW - 4 * lq);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int o = c + 240 * j, kk = j < 2 ? 4 * lq + o : PN_WINDOW - 4 * lq - o;
+          float2 x = j < 2 ? Yd[o] : Ym[-o];
+          if (kk >= PN_SPEC_BINS) x = make_float2(0.f, 0.f);
+          if (j == 3 || (j == 2 && (c > 0 || lq > 0))) x.y = -x.y;
+          fin[c][j] = x;
+        }
+      PN_WAVE_SYNC();                                       // every input is in registers: the first stage may overwrite the parked bins
+      if (lane < 60) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          fs_bfly4_m1(fin[c]);
+          float4 *dst = reinterpret_cast<float4 *>(W.fft + Z.p1off[c]);
+          dst[0] = make_float4(fin[c][0].x, fin[c][0].y, fin[c][1].x, fin[c][1].y);
+          dst[1] = make_float4(fin[c][2].x, fin[c][2].y, fin[c][3].x, fin[c][3].y);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // the twiddle loads of the next passes stay behind the 32 input registers
     float2 w[3][5];
     fs_fft_p23<true>(W.fft, T, lane, w);
     // reversed read-out x960 (318-323), window, overlap-add (352-359): output p = u + 64b + 192c of the transform is
