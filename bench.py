@@ -314,7 +314,7 @@ def pmc_kernel_counters(kernel_prefix, tag=""):
 SPEC_OUT_FIXED = 3200 + 288 + 3200 + 512 + 4          # X + two band-energy rows read | comb-filtered spectrum + feature row + silence flag written
 
 
-def dsp_roofline(kt, B, tag="", periods=None):
+def dsp_roofline(kt, B, tag="", periods=None, silent=None):
     """HBM roofline of the DSP kernels, ONE OBJECT PER KERNEL: `achieved` = algorithmic bytes of that kernel / its HIP-event
     time; `traffic` = HBM-side bytes per launch from the rocprofv3 counters of the same kernels (FETCH_SIZE x 2 — the gfx950
     counter tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 B, MI355X_MICROARCH.md; calibrated for this
@@ -344,6 +344,14 @@ def dsp_roofline(kt, B, tag="", periods=None):
                 extra["algorithmic_bytes_source"] = "sum over this run's streams of (960 + 6 T) * 4 (T = the period the last frame filtered at) + fixed rows"
             else:
                 extra["algorithmic_bytes_source"] = "worst case (T = 768): the run's periods were not read"
+        if fam == "backend" and silent is not None:
+            # round 6: a stream whose frame is silent skips pitch_filter (reference denoise.cpp:536-538) and the kernel no longer
+            # fetches its comb-filtered spectrum P (3200 B): the algorithmic bytes follow from the run's own silence flags (the
+            # synthetic suite keeps 5 % loud streams; by the reference's 1/960^2 silence test every other stream is "silent")
+            extra["algorithmic_bytes_all_streams_non_silent"] = alg
+            extra["silent_streams"] = int(silent)
+            alg -= int(silent) * 3200
+            extra["algorithmic_bytes_source"] = "P (3200 B) counted for the non-silent streams of this run's last frame only"
         o = {"kernel": kname, "bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": alg,
              "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
              "frac": round(alg / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
@@ -383,6 +391,14 @@ def read_periods(ctx, B):
     try:
         return np.frombuffer(ctx.debug_copy(13, B).tobytes(), dtype=np.int32).copy()
     except Exception:                         # noqa: BLE001 — the roofline then falls back to the worst case and says so
+        return None
+
+
+def read_silent(ctx, B):
+    """How many streams the context's last frame flagged silent (they skip pitch_filter and the back end's read of P)."""
+    try:
+        return int((ctx.read_features()[1] != 0).sum())
+    except Exception:                         # noqa: BLE001 — the back end's algorithmic bytes then count P for every stream
         return None
 
 
@@ -470,6 +486,7 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
         kt = ctx.kernel_times()
         desc = ctx.describe()
         periods = read_periods(ctx, B)
+        silent = read_silent(ctx, B)
     finally:
         ctx.close()
     # a SMALL batch is a latency figure: ms_per_step is the result, and a "streams" number would be an extrapolation of a
@@ -486,7 +503,7 @@ def side_config(api, synth, torch, model, dev, stream, B, K, W, nn_mode, label, 
             "kernels_ms_with_events": {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()},
             "dtype": DTYPE_OF_MODE[nn_mode],
             "roofline": gru_roofline(kt, B, nn_mode == api.NN_MFMA_F16, desc, 1, B * K / dt, traffic_tag=traffic_tag),
-            "dsp_roofline": dsp_roofline(kt, B, traffic_tag, periods),
+            "dsp_roofline": dsp_roofline(kt, B, traffic_tag, periods, silent),
             "whole_pipeline_hbm": {"algorithmic_gbs": round(B * K / dt * (62608 + 31850256 / B) / 1e9, 1),
                                    "frac_of_peak": round(B * K / dt * (62608 + 31850256 / B) / 1e12 / PEAK_HBM_TBS, 4),
                                    "note": "SURVEY 8(d): bytes(B) = 62 608 + 31 850 256 / B per stream-frame at the measured rate"}}
@@ -789,6 +806,7 @@ def main():
     kt = {} if a.no_profile else ctx.kernel_times()
     checksum = int(out.to(torch.int64).abs().sum().item())     # keeps the result live / sanity
     periods = read_periods(ctx, B)                              # the periods this run's last frame filtered at (dsp_roofline)
+    silent = read_silent(ctx, B)                                # ... and how many streams it flagged silent (back end: no P read)
     if os.environ.get("PN_BENCH_DUMP"):                         # debugging aid: last frame's PCM of this rank
         import numpy as _np
         _np.save(os.environ["PN_BENCH_DUMP"], out.cpu().numpy())
@@ -913,7 +931,7 @@ def main():
             rl = gru_roofline(kt, B, a.fp16, desc, n_gpus, fps, traffic_tag=tag)
             if rl:
                 res["roofline"] = rl
-            res["dsp_roofline"] = dsp_roofline(kt, B, tag, periods)
+            res["dsp_roofline"] = dsp_roofline(kt, B, tag, periods, silent)
         res.update(fields)                       # numa, sustained_ranks, realtime_ranks, realtime_all_ranks, cpu_baseline: the same keys at any N
         if sustained is not None:
             res["sustained"] = sustained

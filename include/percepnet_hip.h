@@ -93,7 +93,9 @@ size_t pn_ctx_device_bytes(const pn_ctx *ctx);       /* HBM footprint of state +
 size_t pn_ctx_weight_bytes(const pn_ctx *ctx);
 /* Which kernel families this context launches (chosen at creation from its batch size and nn_mode), as a
    NUL-terminated "key=value ..." string, e.g. "nn=mfma_f32 dense=batch gru=batch gru_rb=batch narrow=n16 frontend=split".
-   Returns the length written (excluding the NUL) or -1. */
+   gru / gru_rb: small | batch | direct_rows32 | direct_rows64 (fp32 mode from 24 576 streams: the GRU steps read fragment-order
+   fp32 shadows of their inputs, +19 KB of device memory per stream, results bit-identical) | x3_* / f16_* in the shadow-operand
+   modes; narrow: n16 | batch | small | fc_gb:n48+fc_rb:batch.  Returns the length written (excluding the NUL) or -1. */
 int pn_ctx_describe(const pn_ctx *ctx, char *buf, size_t buf_bytes);
 
 /* Advance every stream by one frame.  Device-resident buffers, asynchronous on the context's

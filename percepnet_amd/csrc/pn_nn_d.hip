@@ -1,14 +1,14 @@
-// Direct-operand fp32 network kernels for gfx950: the large-batch family of nn_mode PN_NN_MFMA (round 6).
+// Direct-operand fp32 GRU kernels for gfx950: the GRU steps of large PN_NN_MFMA contexts (round 6; default from 24 576 streams).
 //
-// Same arithmetic as pn_nn.hip — every layer a GEMM on v_mfma_f32_32x32x2_f32, streams on the M axis, bias preload, one
-// k-ascending chain per output element, the reset-after GRU's four accumulators (compute_gru, reference nnet.cpp:120-180;
-// compute_dense / compute_conv1d nnet.cpp:105-118,182-200; order of sgemv_accum, vec.h:102-135), the same gating epilogue
-// (pn_gru_gate16) — so the results are bit-identical to the batch and small-batch families.  What differs is how the
-// operands reach the matrix pipe.  In pn_nn.hip a wave owns 32 rows and both operands go through LDS: per 48 MFMAs
-// (one 32-k tile) a wave issues 16 ds_read_b128, 11 ds_write, 7 global loads and one block barrier, and the kernels stop at
-// 0.83-0.84 of the fp32 matrix peak with nothing left to hide (NOTES_history.md: staging 1.2 %, the rest LDS operand reads
-// and barriers).  A wave's activation rows are private to it — LDS only TRANSPOSES them into fragment order.  Here:
-//   * every producing layer also writes its output as a FRAGMENT-ORDER fp32 shadow
+// Same arithmetic as pn_gru_mfma_p_kernel (pn_nn.hip) — a GEMM on v_mfma_f32_32x32x2_f32 with the streams on the M axis, bias
+// preload, one k-ascending chain per output element, the reset-after GRU's four accumulators (compute_gru, reference
+// nnet.cpp:120-180; order of sgemv_accum, vec.h:102-135), the same gating epilogue (pn_gru_gate16) — so the results are
+// bit-identical to the batch and small-batch families.  What differs is how the operands reach the matrix pipe.  In pn_nn.hip a
+// wave owns 32 rows and both operands go through LDS: per 48 MFMAs (one 32-k tile) a wave issues 16 ds_read_b128, 11 ds_write,
+// 7 global loads and one block barrier.  But a wave's activation rows are private to it — LDS only TRANSPOSES them into fragment
+// order.  Here:
+//   * the layers that feed a GRU step (conv2 through pn_dense_mfma_ps_kernel, the GRU steps themselves) also write their output
+//     as a FRAGMENT-ORDER fp32 shadow
 //       shadow[M tile of 128][column tile of 32][q 0..3][kh 0..1][row 0..127][4 floats: k = 32 ct + 8 q + 2 s + kh, s = 0..3]
 //     (16 KB per (M tile, column tile); the same slab indexing j * 128 + row, j = 0..7, as the fp16 hi/lo shadows of
 //     pn_nn_x3.hip, so the per-stream reset / active-set code is shared), and a wave loads its A fragments from it
@@ -17,9 +17,11 @@
 //   * a wave owns 64 rows (two 32-row groups): every weight fragment read from LDS feeds 8 MFMAs instead of 4;
 //   * the weight tiles (packed in fragment order by pn_pack_weights) are copied linearly into a double-buffered LDS
 //     image and read back lane-linear (conflict-free ds_read_b128).
-// Per wave and 32-k tile of a GRU step: 96 MFMAs, 12 ds_read_b128, 3 ds_write_b128, 11 global loads, one barrier —
-// per MFMA 2.7x fewer LDS reads, 7x fewer LDS writes and half the barriers of the batch kernels.
-// Block = 4 waves x 64 rows = 256 streams x (NT column tiles of 32 | the three gate tiles of one GRU column tile).
+// Per wave and 32-k tile: 96 MFMAs, 12 ds_read_b128, 3 ds_write_b128, 11 global loads, one barrier — per MFMA 2.7x fewer LDS
+// reads, 7x fewer LDS writes and half the barriers of the batch kernel.  Block = 4 waves x 64 rows = 256 streams x the three gate
+// tiles of one 32-neuron column tile.  Measured (profiles/r06_direct_operand_gru.log): the 512 -> 512 step 1.552 -> 1.523 ms at
+// 65 536 streams; what is left above the matrix-pipe time is the activation loads (3.8 %: VMEM issued by the wave that feeds the
+// pipe) and the gating epilogue (2.7 %).  The dense layers were built in this form too and gained nothing: they stay in pn_nn.hip.
 #include "pn_nn_common.h"
 #include <stdlib.h>
 

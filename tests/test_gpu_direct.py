@@ -1,10 +1,11 @@
-"""Direct-operand fp32 network kernels (percepnet_amd/csrc/pn_nn_d.hip; -m gpu): the large-batch family of nn_mode NN_MFMA.
+"""Direct-operand fp32 GRU kernels (percepnet_amd/csrc/pn_nn_d.hip) and fc_gb on 16x16x4 batch tiles (pn_nn_n48.hip); -m gpu.
 
-They evaluate the same k-ascending fmaf chains as the batch-GEMM and small-batch families (compute_dense / compute_conv1d /
-compute_gru, reference src/nnet.cpp:105-200; order of sgemv_accum, src/vec.h:102-135) with the activations taken from
-fragment-order fp32 shadows instead of through LDS, so every output must be BIT-IDENTICAL to the batch family's — on ragged
-batches, with 32 and 64 rows per wave, as row-range chains, and through every call that touches the network state (per-stream
-reset, the active set, state load / store): the shadows are a second copy of that state and must follow it."""
+From 24 576 streams the GRU steps of nn_mode NN_MFMA evaluate the same k-ascending fmaf chains as the batch-GEMM and small-batch
+families (compute_gru, reference src/nnet.cpp:120-180; order of sgemv_accum, src/vec.h:102-135) with the activations taken from
+fragment-order fp32 shadows instead of through LDS (conv2's batch kernel and the GRU steps write them), so every output must be
+BIT-IDENTICAL to the batch family's — on ragged batches, with 32 and 64 rows per wave, as row-range chains, and through every
+call that touches the network state (per-stream reset, the active set, state load / store): the shadows are a second copy of that
+state and must follow it."""
 import numpy as np
 import pytest
 
@@ -72,8 +73,8 @@ def test_direct_family_is_bit_identical_to_the_batch_family(model, oracle, monke
 
 def test_direct_family_as_row_range_chains(model, monkeypatch):
     """8192 + 300 streams as one, two and three (capped to two) row-range chains, 64 rows per wave: the chains' shares are whole
-    256-row blocks (4352 + 4140), a block past a chain's last row stores nothing, and the fc layer's shadow is written for
-    exactly the chain's rows — bit-identical to the batch family on one stream."""
+    256-row blocks (4352 + 4140) and a block past a chain's last row stores nothing (neither rows nor shadow entries: they are the
+    other chain's) — bit-identical to the batch family on one stream."""
     B, T = 8192 + 300, 5
     pool = synth.synth_batch(64, T)
     pcm = pool[np.arange(B) % 64].copy()
@@ -97,7 +98,7 @@ def test_direct_family_shadows_follow_every_state_change(model, monkeypatch):
     """One scenario through both families, compared tick by tick: 300 streams x 40 ticks with a per-stream reset at tick 7
     (slots 5, 130, 299), streams 17 / 200 / 299 skipping ticks through the active set (every ring phase crossed), the network
     state replaced by random values at tick 20 (pn_ctx_set_rnn_state_host) and a whole-context reset at tick 30.  The fp32
-    shadows are a second copy of the conv FIFOs and GRU states: any call that forgets them shows up as a difference."""
+    shadows are a second copy of the GRU states: any call that forgets them shows up as a difference."""
     import torch
     B, T = 300, 40
     skips = {17: {10, 11, 25}, 200: {11, 21}, 299: {0, 22, 39}}
