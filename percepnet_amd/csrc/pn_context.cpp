@@ -676,7 +676,10 @@ static int nn_chains_of(const pn_ctx *c) {
   // 61 440, 69 632 and every size off the 4096-stream grid, and change nothing at 32 768 / 65 536 (+-0.03 ms) — where a second compute
   // stream would only be one more hardware queue for the pipelined host path's copy streams to stay clear of (HIP has four by default)
   const size_t mt = ((size_t)c->B + 127) / 128;
-  const bool exact = (c->B % 32768 == 0) && (mt <= 512 || mt % 512 == 0);
+  // (second session of round 6: with the direct-operand GRU kernels — 256-row blocks, 8 instead of 16 rounds per 512-wide layer at
+  // 65 536 streams, longer drains — two chains win at the exact fits from 65 536 streams too: 9.02 / 9.03 / 9.07 -> 8.93 / 8.99 / 8.96 ms
+  // per frame at 65 536, 17.99 -> 17.85 at 131 072, even at 32 768; profiles/r06_direct_operand_gru.log H)
+  const bool exact = (c->B % 32768 == 0) && (mt <= 512 || mt % 512 == 0) && !(c->direct && c->B >= 65536);
   int n = e ? atoi(e) : ((c->B > 16384 && !exact) ? 2 : 1);
   if (n < 1) n = 1;
   if (n > PN_MAX_CHAINS) n = PN_MAX_CHAINS;

@@ -30,6 +30,10 @@
 #ifndef PN_D_ABL
 #define PN_D_ABL 0
 #endif
+#ifndef PN_D_REFILL_IDLE
+#define PN_D_REFILL_IDLE 1              // 64-row waves: a tile's activation loads go to the register set the current tile does not read
+#endif
+
 #if PN_D_ABL & 4
 #define D_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -71,7 +75,7 @@ __device__ __forceinline__ void d_load_A(DA<RG> &a, d_gptr pt, unsigned lb, int 
 // refilled from the tile at pf (two tiles ahead) as soon as its last MFMA has issued; mid(i) runs after group i (the
 // caller's weight staging rides there, in the shadow of the MFMAs, instead of after the tile).
 template <int RG, int NT, int I0, int I1, int I2, int I3, class Mid>
-__device__ __forceinline__ void d_tile(DA<RG> &a, const fvec4 (*Bs)[256], d_gptr pf, unsigned lb, int lane,
+__device__ __forceinline__ void d_tile(DA<RG> &a, DA<RG> &fill, const fvec4 (*Bs)[256], d_gptr pf, unsigned lb, int lane,
                                        floatx16 (&acc)[RG][4], Mid &&mid) {
   constexpr int IDX[4] = {I0, I1, I2, I3};
   fvec4 f0 = Bs[0][lane], f1;
@@ -93,7 +97,7 @@ __device__ __forceinline__ void d_tile(DA<RG> &a, const fvec4 (*Bs)[256], d_gptr
     __builtin_amdgcn_sched_barrier(0);
 #if !(PN_D_ABL & 1)
     if (t == NT - 1) {
-      d_load_A<RG>(a, pf, lb, q);
+      d_load_A<RG>(fill, pf, lb, q);
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
@@ -151,15 +155,21 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_d_kernel(
     const size_t bo_ = (size_t)(p1_ ? g_ : g_ - T1) * 1024; \
     D_BLOAD(rb[0], (p1_ ? Wz : Uz) + bo_); D_BLOAD(rb[1], (p1_ ? Wr : Ur) + bo_); D_BLOAD(rb[2], (p1_ ? Wh : Uh) + bo_); } while (0)
 #define DG_BSTASH(buf) do { D_BSTASH(buf, 0, rb[0]); D_BSTASH(buf, 1, rb[1]); D_BSTASH(buf, 2, rb[2]); } while (0)
+  // Where the activation loads issued during a tile land.  64-row waves: in the register set the current tile does NOT read — tile
+  // g + 1, one tile (>= 6144 matrix-pipe cycles) ahead; no load ever targets a register an in-flight MFMA still reads: gru512 -0.4 %
+  // (profiles/r06_direct_operand_gru.log G).  32-row waves (a tile is half as long, three waves per SIMD): the slab just consumed is
+  // refilled with tile g + 2, two tiles ahead, as in pn_nn_x3.hip.  (A raised wave priority for the K loop: +0.8 %, not kept.)
+  constexpr bool IDLE = PN_D_REFILL_IDLE && RG == 2;
+#define DG_FILL(cur, other) (IDLE ? other : cur)
 #define DG_PAIR(g, I2)                                                                                             \
-    { DG_APTR(pa); d_tile<RG, 3, 0, 1, I2, 0>(qa, S.B[0], pa, lb, lane, acc, [&](int i) { if (!(PN_D_ABL & 2)) { if (i == 1) DG_BSTASH(1); if (i == 3) DG_BLOAD((g) + 2); } }); } \
+    { DG_APTR(pa); d_tile<RG, 3, 0, 1, I2, 0>(qa, DG_FILL(qa, qb), S.B[0], pa, lb, lane, acc, [&](int i) { if (!(PN_D_ABL & 2)) { if (i == 1) DG_BSTASH(1); if (i == 3) DG_BLOAD((g) + 2); } }); } \
     D_SYNC();                                                                                                      \
-    { DG_APTR(pb); d_tile<RG, 3, 0, 1, I2, 0>(qb, S.B[1], pb, lb, lane, acc, [&](int i) { if (!(PN_D_ABL & 2)) { if (i == 1) DG_BSTASH(0); if (i == 3) DG_BLOAD((g) + 3); } }); } \
+    { DG_APTR(pb); d_tile<RG, 3, 0, 1, I2, 0>(qb, DG_FILL(qb, qa), S.B[1], pb, lb, lane, acc, [&](int i) { if (!(PN_D_ABL & 2)) { if (i == 1) DG_BSTASH(0); if (i == 3) DG_BLOAD((g) + 3); } }); } \
     D_SYNC()
   DA<RG> qa, qb;
   fvec4 rb[3];
   { DG_APTR(p0); _Pragma("unroll") for (int q = 0; q < 4; q++) d_load_A<RG>(qa, p0, lb, q); }
-  { DG_APTR(p1); _Pragma("unroll") for (int q = 0; q < 4; q++) d_load_A<RG>(qb, p1, lb, q); }
+  if (!IDLE) { DG_APTR(p1); _Pragma("unroll") for (int q = 0; q < 4; q++) d_load_A<RG>(qb, p1, lb, q); }
   DG_BLOAD(0); DG_BSTASH(0); DG_BLOAD(1);
   if (tid < 201) S.tansig[tid] = ts_v;
   __syncthreads();
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(NN_THREADS, 4 - RG) void pn_gru_d_kernel(
   for (int g = 0; g < T1; g += 2) { DG_PAIR(g, 2); }
 #pragma unroll 1
   for (int g = T1; g < TT; g += 2) { DG_PAIR(g, 3); }
+
 #undef DG_PAIR
 #undef DG_BSTASH
 #undef DG_BLOAD
