@@ -185,6 +185,9 @@ def test_stall_run_verdict_checks_deliveries_after_the_recovery_point():
     assert rtc.stall_verdict(backlog, late, lat, at, 25.0)["recovered"] is False        # ended behind its clock
     early = lat.copy(); early[40] = 30.0                                               # a late frame BEFORE the stall: not a clean run
     assert rtc.stall_verdict(backlog, late, early, at, 1.0)["recovered"] is False
+    warm = backlog.copy(); warm[3] = 0.0007                                            # a submit call that woke 0.7 ms late before the stall: jitter
+    v = rtc.stall_verdict(warm, late, lat, at, 1.0)
+    assert v["recovered"] is True and v["jitter_frames_before_the_stall"] == 1 and v["clean_before_the_stall"] is True
 
 
 REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -100,13 +100,14 @@ def stall_verdict(backlog_s, late_s, latency_ms, stall_at, finished_behind_ms):
     after DELIVERY_DEADLINE_MS or never.  The stall's burst ends — the RECOVERY POINT — at the first frame from which 20 consecutive
     frames are undisturbed: submits on their arrivals AND deliveries in time again (advisor, round 5: the verdict used to look at the
     submit clock alone — the device queue drains for another 6-12 frames after the submit clock is back).
-    recovered = the run was clean before the stall, the recovery point lies within RECOVERY_FRAMES of it, and from there to the end
+    recovered = no contract violation before the stall, the recovery point lies within RECOVERY_FRAMES of it, and from there to the end
     the run meets the CONTRACT of an undisturbed run frame by frame — no back-pressure miss, every frame delivered within the deadline
     — and ends on its clock.  (Until the second session of round 6 the recovery point was the frame after the LAST frame with a
     submit backlog >= 0.5 ms anywhere in the run: one submit call that woke 0.6 ms late hundreds of frames after a completed recovery
     — host jitter that every undisturbed run tolerates, the frame still submitted before the next arrival and delivered in time —
-    failed the run; it did so on one box of five.  Such frames are now counted in `jitter_frames_after_recovery`, contract
-    violations after the recovery point still fail the run.)  `frames_to_recover_submit_clock` keeps the oldest measure."""
+    failed the run, and so did one such wake-up BEFORE the stall; it happened on two boxes of seven.  Such frames are now counted
+    (`jitter_frames_after_recovery`, `jitter_frames_before_the_stall`); contract violations before the stall or after the recovery
+    point still fail the run.)  `frames_to_recover_submit_clock` keeps the oldest measure."""
     import numpy as np
     backlog_s, late_s = np.asarray(backlog_s, dtype=float), np.asarray(late_s, dtype=float)
     lat = np.asarray(latency_ms, dtype=float)
@@ -114,7 +115,7 @@ def stall_verdict(backlog_s, late_s, latency_ms, stall_at, finished_behind_ms):
     after = np.nonzero(backlog_s[stall_at + 1:] < 0.0005)[0]
     violation = (late_s > 0) | (np.nan_to_num(lat, nan=1e12) > DELIVERY_DEADLINE_MS)          # what an undisturbed run may not do either
     disturbed = (backlog_s >= 0.0005) | violation
-    clean_before = not bool(disturbed[:stall_at].any())                                     # anything before the stall is not the stall's: it fails the run
+    clean_before = not bool(violation[:stall_at].any())     # a contract violation before the stall is not the stall's: it fails the run (submit jitter is counted)
     calm = ~disturbed
     point = None                                           # first frame >= stall_at that starts 20 undisturbed frames
     run = 0
@@ -132,6 +133,7 @@ def stall_verdict(backlog_s, late_s, latency_ms, stall_at, finished_behind_ms):
             "clean_frames_after_recovery": int(n - point) if point is not None else 0,
             "contract_violations_after_recovery": bad_after,
             "jitter_frames_after_recovery": int((disturbed[point:] & ~violation[point:]).sum()) if point is not None else None,
+            "jitter_frames_before_the_stall": int((disturbed[:stall_at] & ~violation[:stall_at]).sum()),
             "delivery_p99_ms_after_recovery": round(float(np.percentile(tail, 99)), 4) if tail.size and not np.isnan(tail).any() else None,
             "clean_before_the_stall": clean_before}
 
